@@ -1,0 +1,489 @@
+/*
+ * admm_oracle.c -- TEST INFRASTRUCTURE ONLY (see admm_oracle.h).
+ *
+ * Scalar restatement of the reference's ADMM hot path.  Every function cites
+ * the reference lines it follows.  The arithmetic types are the reference's:
+ * state is binary32, log/exp are the double libm functions with the result
+ * rounded to float where the reference stores into a float, and no operation
+ * is fused (build with -ffp-contract=off; the reference's x86-64 build emits
+ * no FMA).
+ */
+#include "admm_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORACLE_EPSILON 0.00000000000000001 /* Tree.h:15 */
+
+/* ------------------------------------------------------------------ */
+/* synthetic inputs                                                     */
+/* ------------------------------------------------------------------ */
+
+unsigned oracle_lcg_fill(unsigned state, long long n, float *out) {
+  for (long long i = 0; i < n; i++) {
+    state = state * 1664525u + 1013904223u;
+    out[i] = (float)(state >> 8) / 16777216.0f;
+  }
+  return state;
+}
+
+int oracle_grid_edges(int R, int C, int *edgeList) {
+  int e = 0;
+  for (int r = 0; r < R; r++) {
+    for (int c = 0; c + 1 < C; c++) { /* Grid.cpp:585-596 */
+      edgeList[2 * e] = r * C + c;
+      edgeList[2 * e + 1] = r * C + c + 1;
+      e++;
+    }
+    if (r == R - 1) break; /* Grid.cpp:598-600 */
+    for (int c = 0; c < C; c++) { /* Grid.cpp:605-614 */
+      edgeList[2 * e] = r * C + c;
+      edgeList[2 * e + 1] = (r + 1) * C + c;
+      e++;
+    }
+  }
+  return e;
+}
+
+/* ------------------------------------------------------------------ */
+/* edge solver                                                          */
+/* ------------------------------------------------------------------ */
+
+struct oracle_edge {
+  int V, E, k, k2;
+  float penalty, penaltyPrime, rho;
+  int *edgeList;
+  int *vertCnt;
+  float *vertPot, *edgePot;
+  float *mu_node, *pot_node, *m_node, *lambda_node; /* E*2k */
+  float *mu_edge, *pot_edge;                        /* E*k2 */
+  float *vertMu;                                    /* V*k  */
+};
+
+static float *falloc(long long n) { return (float *)calloc((size_t)(n > 0 ? n : 1), sizeof(float)); }
+
+oracle_edge *oracle_edge_create(int V, int E, int k, const int *edgeList,
+                                const float *vertPot, const float *edgePot,
+                                float penalty, float penaltyPrime, float rho) {
+  oracle_edge *o = (oracle_edge *)calloc(1, sizeof(*o));
+  o->V = V; o->E = E; o->k = k; o->k2 = k * k;
+  o->penalty = penalty; o->penaltyPrime = penaltyPrime; o->rho = rho;
+  o->edgeList = (int *)malloc(sizeof(int) * 2 * (size_t)(E > 0 ? E : 1));
+  memcpy(o->edgeList, edgeList, sizeof(int) * 2 * (size_t)E);
+  o->vertCnt = (int *)calloc((size_t)(V > 0 ? V : 1), sizeof(int));
+  o->vertPot = falloc((long long)V * k);
+  memcpy(o->vertPot, vertPot, sizeof(float) * (size_t)V * k);
+  o->edgePot = falloc((long long)E * o->k2);
+  memcpy(o->edgePot, edgePot, sizeof(float) * (size_t)E * o->k2);
+  o->mu_node = falloc((long long)E * 2 * k);
+  o->pot_node = falloc((long long)E * 2 * k);
+  o->m_node = falloc((long long)E * 2 * k);
+  o->lambda_node = falloc((long long)E * 2 * k);
+  o->mu_edge = falloc((long long)E * o->k2);
+  o->pot_edge = falloc((long long)E * o->k2);
+  o->vertMu = falloc((long long)V * k);
+  return o;
+}
+
+void oracle_edge_destroy(oracle_edge *o) {
+  if (!o) return;
+  free(o->edgeList); free(o->vertCnt); free(o->vertPot); free(o->edgePot);
+  free(o->mu_node); free(o->pot_node); free(o->m_node); free(o->lambda_node);
+  free(o->mu_edge); free(o->pot_edge); free(o->vertMu);
+  free(o);
+}
+
+/* Consensus division, Grid.cpp:176-180: float /= int. */
+static void edge_average(oracle_edge *o) {
+  for (int v = 0; v < o->V; v++)
+    for (int j = 0; j < o->k; j++)
+      o->vertMu[(size_t)v * o->k + j] /= o->vertCnt[v];
+}
+
+void oracle_edge_init(oracle_edge *o) {
+  const int k = o->k, k2 = o->k2;
+  /* copy count per vertex: GetVerts, Grid.cpp:815-856 (one rank: no remote
+   * contribution from Grid.cpp:309-319). */
+  memset(o->vertCnt, 0, sizeof(int) * (size_t)o->V);
+  for (int i = 0; i < 2 * o->E; i++) o->vertCnt[o->edgeList[i]]++;
+  /* Grid.cpp:1478-1484: one add of theta_v per incident endpoint. */
+  memset(o->vertMu, 0, sizeof(float) * (size_t)o->V * k);
+  for (int i = 0; i < 2 * o->E; i++) {
+    int v = o->edgeList[i];
+    for (int j = 0; j < k; j++)
+      o->vertMu[(size_t)v * k + j] += o->vertPot[(size_t)v * k + j];
+  }
+  edge_average(o); /* Grid.cpp:1486-1487 */
+  /* InitTree, Grid.cpp:944-979; initial marginals Tree.cpp:24-33. */
+  const float inv_k = 1.0 / (float)k;
+  const float inv_k2 = 1.0 / (float)k2;
+  for (int e = 0; e < o->E; e++) {
+    int l = o->edgeList[2 * e], r = o->edgeList[2 * e + 1];
+    float *pn = o->pot_node + (size_t)e * 2 * k;
+    for (int j = 0; j < k; j++) {
+      pn[j] = o->vertMu[(size_t)l * k + j] / (o->rho * o->vertCnt[l]);
+      pn[k + j] = o->vertMu[(size_t)r * k + j] / (o->rho * o->vertCnt[r]);
+    }
+    for (int j = 0; j < 2 * k; j++) {
+      o->mu_node[(size_t)e * 2 * k + j] = inv_k;
+      o->m_node[(size_t)e * 2 * k + j] = inv_k;
+      o->lambda_node[(size_t)e * 2 * k + j] = 0.0f;
+    }
+    for (int j = 0; j < k2; j++) {
+      o->pot_edge[(size_t)e * k2 + j] = o->edgePot[(size_t)e * k2 + j] / o->rho;
+      o->mu_edge[(size_t)e * k2 + j] = inv_k2;
+    }
+  }
+}
+
+void oracle_edge_solve_one(int k, float *mu, const float *pot, const float *m,
+                           float *lam, float *mue, const float *pote,
+                           float penalty, float penaltyPrime, float rho,
+                           float *acc_l, float *acc_r) {
+  const int k2 = k * k;
+  float *xnode = (float *)malloc(sizeof(float) * (size_t)(9 * k + 4 * k2));
+  float *nderiv = xnode + 2 * k, *npot = nderiv + 2 * k;
+  float *buf = npot + 2 * k, *m12 = buf + k, *m21 = m12 + k;
+  float *xedge = m21 + k, *ederiv = xedge + k2, *epot = ederiv + k2, *bsq = epot + k2;
+
+  /* UpdateLambda, Tree.cpp:64-73 */
+  for (int j = 0; j < 2 * k; j++) lam[j] += penalty * (mu[j] - m[j]);
+  /* AdjustPotentials, Tree.cpp:78-107 */
+  for (int i = 0; i < 2 * k; i++)
+    xnode[i] = rho * (pot[i] + lam[i]) - penalty * (m[i] - mu[i]);
+  for (int i = 0; i < k2; i++) xedge[i] = rho * pote[i];
+  /* UpdateMu, Tree.cpp:46-57 */
+  for (int i = 0; i < 2 * k; i++) if (mu[i] <= 0.0) mu[i] = ORACLE_EPSILON;
+  for (int i = 0; i < k2; i++) if (mue[i] <= 0.0) mue[i] = ORACLE_EPSILON;
+  /* derivatives, Tree.cpp:118-151 */
+  for (int a = 0; a < k; a++) {
+    float value = log(mu[a]);
+    nderiv[a] = -1.0 - value;
+    for (int b = 0; b < k; b++)
+      ederiv[a * k + b] = value - log(mue[a * k + b]) + 1;
+  }
+  for (int b = 0; b < k; b++) {
+    float value = log(mu[k + b]);
+    nderiv[k + b] = -1.0 - value;
+    for (int a = 0; a < k; a++) ederiv[a * k + b] += value;
+  }
+  /* potentials, Tree.cpp:157-176 */
+  for (int i = 0; i < 2 * k; i++) {
+    float value = xnode[i] + penaltyPrime * nderiv[i];
+    value /= penaltyPrime;
+    npot[i] = 0.0 - value;
+  }
+  for (int i = 0; i < k2; i++) {
+    float value = xedge[i] + penaltyPrime * ederiv[i];
+    value /= penaltyPrime;
+    epot[i] = 0.0 - value;
+  }
+  /* sumProductEdge, Tree.cpp:186-274 */
+  float sum = 0.0;
+  memcpy(bsq, epot, sizeof(float) * (size_t)k2);
+  for (int b = 0; b < k; b++) { /* message 1 -> 2, Tree.cpp:191-205 */
+    buf[b] = 0.0;
+    for (int a = 0; a < k; a++) {
+      buf[b] += exp(epot[a * k + b] + npot[a]);
+      bsq[a * k + b] += npot[a];
+    }
+    sum += buf[b];
+  }
+  for (int b = 0; b < k; b++) m12[b] = buf[b] / sum;
+  sum = 0.0;
+  for (int a = 0; a < k; a++) { /* message 2 -> 1, Tree.cpp:212-229 */
+    buf[a] = 0.0;
+    for (int b = 0; b < k; b++) {
+      buf[a] += exp(epot[a * k + b] + npot[k + b]);
+      bsq[a * k + b] += npot[k + b];
+    }
+    sum += buf[a];
+  }
+  for (int a = 0; a < k; a++) m21[a] = buf[a] / sum;
+  sum = 0.0; /* node marginal 1, Tree.cpp:236-245 */
+  for (int i = 0; i < k; i++) { buf[i] = exp(npot[i]) * m21[i]; sum += buf[i]; }
+  for (int i = 0; i < k; i++) { mu[i] = buf[i] / sum; acc_l[i] += mu[i]; }
+  sum = 0.0; /* node marginal 2, Tree.cpp:246-254 */
+  for (int i = 0; i < k; i++) { buf[i] = exp(npot[i + k]) * m12[i]; sum += buf[i]; }
+  for (int i = 0; i < k; i++) { mu[i + k] = buf[i] / sum; acc_r[i] += mu[i + k]; }
+  for (int a = 0; a < k; a++) { /* edge marginal, Tree.cpp:256-273 */
+    buf[a] = 0.0;
+    for (int b = 0; b < k; b++) {
+      bsq[a * k + b] = exp(bsq[a * k + b]);
+      buf[a] += bsq[a * k + b];
+    }
+    for (int b = 0; b < k; b++) {
+      if (buf[a] != 0.0) mue[a * k + b] = mu[a] * bsq[a * k + b] / buf[a];
+      else mue[a * k + b] = 0.0;
+    }
+  }
+  free(xnode);
+}
+
+void oracle_edge_compute(oracle_edge *o) {
+  const int k = o->k, k2 = o->k2;
+  memset(o->vertMu, 0, sizeof(float) * (size_t)o->V * k); /* Grid.cpp:144-148 */
+  for (int e = 0; e < o->E; e++) {                         /* Grid.cpp:1400-1410 */
+    int l = o->edgeList[2 * e], r = o->edgeList[2 * e + 1];
+    oracle_edge_solve_one(k, o->mu_node + (size_t)e * 2 * k, o->pot_node + (size_t)e * 2 * k,
+                          o->m_node + (size_t)e * 2 * k, o->lambda_node + (size_t)e * 2 * k,
+                          o->mu_edge + (size_t)e * k2, o->pot_edge + (size_t)e * k2,
+                          o->penalty, o->penaltyPrime, o->rho,
+                          o->vertMu + (size_t)l * k, o->vertMu + (size_t)r * k);
+  }
+}
+
+void oracle_edge_update(oracle_edge *o) {
+  const int k = o->k;
+  edge_average(o); /* Grid.cpp:163-181, no neighbours on one rank */
+  for (int i = 0; i < 2 * o->E; i++) /* Grid.cpp:188-192 */
+    memcpy(o->m_node + (size_t)(i / 2) * 2 * k + (size_t)(i % 2) * k,
+           o->vertMu + (size_t)o->edgeList[i] * k, sizeof(float) * (size_t)k);
+}
+
+double oracle_edge_objective(const oracle_edge *o) {
+  double obj = 0.0; /* Grid.cpp:1665-1680 */
+  for (int e = 0; e < o->E; e++) {
+    for (int j = 0; j < 2 * o->k; j++)
+      obj += o->pot_node[(size_t)e * 2 * o->k + j] * o->mu_node[(size_t)e * 2 * o->k + j];
+    for (int j = 0; j < o->k2; j++)
+      obj += o->pot_edge[(size_t)e * o->k2 + j] * o->mu_edge[(size_t)e * o->k2 + j];
+  }
+  return obj * o->rho;
+}
+
+const int *oracle_edge_vertcnt(const oracle_edge *o) { return o->vertCnt; }
+float *oracle_edge_mu_node(oracle_edge *o) { return o->mu_node; }
+float *oracle_edge_pot_node(oracle_edge *o) { return o->pot_node; }
+float *oracle_edge_m_node(oracle_edge *o) { return o->m_node; }
+float *oracle_edge_lambda_node(oracle_edge *o) { return o->lambda_node; }
+float *oracle_edge_mu_edge(oracle_edge *o) { return o->mu_edge; }
+float *oracle_edge_pot_edge(oracle_edge *o) { return o->pot_edge; }
+float *oracle_edge_vertmu(oracle_edge *o) { return o->vertMu; }
+
+/* ------------------------------------------------------------------ */
+/* chain solver                                                         */
+/* ------------------------------------------------------------------ */
+/*
+ * Trees are the R row chains and the C column chains, so every vertex has
+ * exactly two copies (vertCnt == 2).  The shell is the edge solver's:
+ *   split     theta_tau = theta_v / (rho * 2), W_tau = W / rho   (Grid.cpp:952-977)
+ *   dual      lambda += penalty * (mu - m)                        (Tree.cpp:70)
+ *   adjust    t = rho*(theta_tau + lambda) - penalty*(m - mu)     (Tree.cpp:85-86)
+ *             pairwise = rho * W_tau                              (Tree.cpp:99)
+ *   consensus m_v = (mu_row + mu_col) / 2                         (Grid.cpp:176-180)
+ * and the subproblem is min-sum: forward
+ *   M_0 = t_0,  M_{t+1}[b] = t_{t+1}[b] + min_a (M_t[a] + W[a][b]),
+ * back-pointer = lowest a attaining the minimum, backtrack from the lowest
+ * argmin of the last M.  mu is the one-hot vector of the chain's labels
+ * (before the first solve it is the uniform 1/k of Tree.cpp:24-33, kept as the
+ * label -1).
+ */
+struct oracle_chain {
+  int R, C, k;
+  float penalty, rho;
+  float *theta;    /* V*k, per-copy share */
+  float *Wt;       /* k*k, rho * (W / rho) */
+  float *Wsplit;   /* k*k, W / rho */
+  float *lam_row, *lam_col, *m; /* V*k */
+  int *xrow, *xcol;             /* V */
+  float inv_k;
+};
+
+oracle_chain *oracle_chain_create(int R, int C, int k, const float *unary,
+                                  const float *W, float penalty, float rho) {
+  oracle_chain *o = (oracle_chain *)calloc(1, sizeof(*o));
+  const long long V = (long long)R * C;
+  o->R = R; o->C = C; o->k = k; o->penalty = penalty; o->rho = rho;
+  o->theta = falloc(V * k);
+  memcpy(o->theta, unary, sizeof(float) * (size_t)(V * k));
+  o->Wt = falloc((long long)k * k);
+  o->Wsplit = falloc((long long)k * k);
+  memcpy(o->Wsplit, W, sizeof(float) * (size_t)k * k);
+  o->lam_row = falloc(V * k);
+  o->lam_col = falloc(V * k);
+  o->m = falloc(V * k);
+  o->xrow = (int *)malloc(sizeof(int) * (size_t)(V > 0 ? V : 1));
+  o->xcol = (int *)malloc(sizeof(int) * (size_t)(V > 0 ? V : 1));
+  return o;
+}
+
+void oracle_chain_destroy(oracle_chain *o) {
+  if (!o) return;
+  free(o->theta); free(o->Wt); free(o->Wsplit); free(o->lam_row); free(o->lam_col);
+  free(o->m); free(o->xrow); free(o->xcol); free(o);
+}
+
+void oracle_chain_init(oracle_chain *o) {
+  const long long V = (long long)o->R * o->C;
+  const int k = o->k;
+  const int cnt = 2;
+  for (long long i = 0; i < V * k; i++) {
+    /* Grid.cpp:1478-1487 with two copies, then Grid.cpp:953-956 */
+    float s = 0.0f;
+    s += o->theta[i];
+    s += o->theta[i];
+    s /= cnt;
+    o->theta[i] = s / (o->rho * cnt);
+    o->lam_row[i] = 0.0f;
+    o->lam_col[i] = 0.0f;
+  }
+  o->inv_k = 1.0 / (float)k;
+  for (long long i = 0; i < V * k; i++) o->m[i] = o->inv_k;
+  for (long long i = 0; i < V; i++) { o->xrow[i] = -1; o->xcol[i] = -1; }
+  for (int i = 0; i < k * k; i++) {
+    o->Wsplit[i] = o->Wsplit[i] / o->rho; /* Grid.cpp:975-976 */
+    o->Wt[i] = o->rho * o->Wsplit[i];     /* Tree.cpp:99 */
+  }
+}
+
+static inline float chain_mu(int x, int l, float inv_k) {
+  return x < 0 ? inv_k : (x == l ? 1.0f : 0.0f);
+}
+
+/* One chain of T nodes; node t is first + t*step. */
+static void chain_solve(oracle_chain *o, float *lam, int *x, long long first,
+                        long long step, int T, float *th, float *M, unsigned char *bp) {
+  const int k = o->k;
+  for (int t = 0; t < T; t++) {
+    long long n = first + (long long)t * step;
+    for (int l = 0; l < k; l++) {
+      float mu = chain_mu(x[n], l, o->inv_k);
+      float mv = o->m[n * k + l];
+      float la = lam[n * k + l];
+      la += o->penalty * (mu - mv);
+      lam[n * k + l] = la;
+      th[(size_t)t * k + l] = o->rho * (o->theta[n * k + l] + la) - o->penalty * (mv - mu);
+    }
+  }
+  float *Mn = M + k;
+  for (int b = 0; b < k; b++) M[b] = th[b];
+  for (int t = 1; t < T; t++) {
+    for (int b = 0; b < k; b++) {
+      float best = M[0] + o->Wt[b];
+      int arg = 0;
+      for (int a = 1; a < k; a++) {
+        float c = M[a] + o->Wt[a * k + b];
+        if (c < best) { best = c; arg = a; }
+      }
+      Mn[b] = th[(size_t)t * k + b] + best;
+      bp[(size_t)t * k + b] = (unsigned char)arg;
+    }
+    memcpy(M, Mn, sizeof(float) * (size_t)k);
+  }
+  int cur = 0;
+  for (int b = 1; b < k; b++) if (M[b] < M[cur]) cur = b;
+  for (int t = T - 1; t >= 0; t--) {
+    x[first + (long long)t * step] = cur;
+    if (t > 0) cur = bp[(size_t)t * k + cur];
+  }
+}
+
+void oracle_chain_compute_range(oracle_chain *o, int r0, int r1, int c0, int c1) {
+  const int R = o->R, C = o->C, k = o->k;
+  const int T = R > C ? R : C;
+  float *th = falloc((long long)T * k);
+  float *M = falloc(2LL * k);
+  unsigned char *bp = (unsigned char *)malloc((size_t)T * k + 1);
+  for (int r = r0; r < r1; r++) chain_solve(o, o->lam_row, o->xrow, (long long)r * C, 1, C, th, M, bp);
+  for (int c = c0; c < c1; c++) chain_solve(o, o->lam_col, o->xcol, c, C, R, th, M, bp);
+  free(th); free(M); free(bp);
+}
+
+void oracle_chain_compute(oracle_chain *o) { oracle_chain_compute_range(o, 0, o->R, 0, o->C); }
+
+void oracle_chain_update_range(oracle_chain *o, int r0, int r1, int c0, int c1) {
+  const int k = o->k;
+  for (int r = r0; r < r1; r++)
+    for (int c = c0; c < c1; c++) {
+      long long n = (long long)r * o->C + c;
+      for (int l = 0; l < k; l++) {
+        float s = 0.0f;
+        s += chain_mu(o->xrow[n], l, o->inv_k);
+        s += chain_mu(o->xcol[n], l, o->inv_k);
+        s /= 2; /* Grid.cpp:178 */
+        o->m[n * k + l] = s;
+      }
+    }
+}
+
+void oracle_chain_update(oracle_chain *o) { oracle_chain_update_range(o, 0, o->R, 0, o->C); }
+
+static inline int chain_decode(int xr, int xc) {
+  /* argmax of m_v with the lowest index winning ties */
+  if (xr < 0 || xc < 0) return 0;
+  return xr < xc ? xr : xc;
+}
+
+void oracle_chain_labels(const oracle_chain *o, int *labels) {
+  const long long V = (long long)o->R * o->C;
+  for (long long n = 0; n < V; n++) labels[n] = chain_decode(o->xrow[n], o->xcol[n]);
+}
+
+void oracle_chain_objective(const oracle_chain *o, double *primal, double *dual, double *linear) {
+  const int R = o->R, C = o->C, k = o->k;
+  if (primal) {
+    double p = 0.0;
+    for (int r = 0; r < R; r++)
+      for (int c = 0; c < C; c++) {
+        long long n = (long long)r * C + c;
+        int x = chain_decode(o->xrow[n], o->xcol[n]);
+        p += (double)o->theta[n * k + x];
+        p += (double)o->theta[n * k + x];
+        if (c + 1 < C) p += (double)o->Wsplit[x * k + chain_decode(o->xrow[n + 1], o->xcol[n + 1])];
+        if (r + 1 < R) p += (double)o->Wsplit[x * k + chain_decode(o->xrow[n + C], o->xcol[n + C])];
+      }
+    *primal = p * o->rho;
+  }
+  if (linear) {
+    double p = 0.0;
+    for (int r = 0; r < R; r++)
+      for (int c = 0; c < C; c++) {
+        long long n = (long long)r * C + c;
+        int xr = o->xrow[n] < 0 ? 0 : o->xrow[n], xc = o->xcol[n] < 0 ? 0 : o->xcol[n];
+        p += (double)o->theta[n * k + xr];
+        p += (double)o->theta[n * k + xc];
+        if (c + 1 < C) p += (double)o->Wsplit[xr * k + (o->xrow[n + 1] < 0 ? 0 : o->xrow[n + 1])];
+        if (r + 1 < R) p += (double)o->Wsplit[xc * k + (o->xcol[n + C] < 0 ? 0 : o->xcol[n + C])];
+      }
+    *linear = p * o->rho;
+  }
+  if (dual) {
+    double d = 0.0;
+    float *M = falloc(2LL * k);
+    float *Mn = M + k;
+    for (int pass = 0; pass < 2; pass++) {
+      const float *lam = pass == 0 ? o->lam_row : o->lam_col;
+      int nch = pass == 0 ? R : C, T = pass == 0 ? C : R;
+      for (int ch = 0; ch < nch; ch++) {
+        long long first = pass == 0 ? (long long)ch * C : ch, step = pass == 0 ? 1 : C;
+        for (int b = 0; b < k; b++) M[b] = o->theta[first * k + b] + lam[first * k + b];
+        for (int t = 1; t < T; t++) {
+          long long n = first + (long long)t * step;
+          for (int b = 0; b < k; b++) {
+            float best = M[0] + o->Wsplit[b];
+            for (int a = 1; a < k; a++) {
+              float c = M[a] + o->Wsplit[a * k + b];
+              if (c < best) best = c;
+            }
+            Mn[b] = (o->theta[n * k + b] + lam[n * k + b]) + best;
+          }
+          memcpy(M, Mn, sizeof(float) * (size_t)k);
+        }
+        float best = M[0];
+        for (int b = 1; b < k; b++) if (M[b] < best) best = M[b];
+        d += (double)best;
+      }
+    }
+    free(M);
+    *dual = d * o->rho;
+  }
+}
+
+int *oracle_chain_xrow(oracle_chain *o) { return o->xrow; }
+int *oracle_chain_xcol(oracle_chain *o) { return o->xcol; }
+float *oracle_chain_consensus(oracle_chain *o) { return o->m; }
+float *oracle_chain_lambda_row(oracle_chain *o) { return o->lam_row; }
+float *oracle_chain_lambda_col(oracle_chain *o) { return o->lam_col; }
+float *oracle_chain_theta(oracle_chain *o) { return o->theta; }
