@@ -1,0 +1,890 @@
+// C ABI of libadmm_hip.so (see include/admm_hip.h): context management, data
+// movement and kernel launches for the two subproblem solvers.
+#include "../../include/admm_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "chain_kernels.hpp"
+#include "edge_kernels.hpp"
+
+using namespace admm;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Strip {
+  int row0 = 0, nrows = 0, col0 = 0, ncols = 0;
+};
+
+}  // namespace
+
+struct admm_ctx {
+  admm_desc d{};
+  std::string err;
+  hipStream_t stream = nullptr;
+  bool have_unary = false, have_pair = false, inited = false;
+  std::vector<void *> allocs;
+
+  // ---- edge solver ----
+  int V = 0, E = 0;
+  std::vector<int> h_edges, h_inc_off, h_inc;
+  int *d_edges = nullptr, *d_inc_off = nullptr, *d_inc = nullptr;
+  float *d_vert_pot = nullptr, *d_edge_pot = nullptr;
+  int pair_per_edge = 0;
+  float *d_mu_node = nullptr, *d_pot_node = nullptr, *d_lam_node = nullptr;
+  float *d_mu_edge = nullptr, *d_pot_edge = nullptr, *d_m_vert = nullptr;
+  double *d_partial = nullptr;
+  int n_partial = 0;
+
+  // ---- chain solver ----
+  Strip st;
+  int KP = 0;
+  float inv_k = 0.f;
+  // row strip: [batch][nrows][cols][k]; column strip: [batch][rows][ncols][k].
+  // With one strip the column-side pointers alias the row-side ones.
+  float *th_r = nullptr, *lam_r = nullptr, *m_r = nullptr;
+  float *th_c = nullptr, *lam_c = nullptr, *m_c = nullptr;
+  int *xrow_r = nullptr;   // [batch][nrows][cols]   labels of my row chains
+  int *xcolT_r = nullptr;  // [batch][cols][nrows]   column-chain labels on my rows
+  int *xrow_c = nullptr;   // [rows][ncols]          row-chain labels on my columns
+  int *xcolT_c = nullptr;  // [ncols][rows]          labels of my column chains
+  uint8_t *bp_r = nullptr, *bp_c = nullptr;
+  float *d_W = nullptr, *d_Wsplit = nullptr, *d_Wt = nullptr;
+  float *d_chain_min = nullptr;
+  int *sendbuf = nullptr;
+  std::vector<float> h_unary_stage;
+
+  ncclComm_t comm = nullptr;
+
+  // ---- profiling ----
+  bool prof = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  size_t prof_used = 0;
+};
+
+namespace {
+
+int fail(admm_ctx *c, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_create_error = buf;
+  return code;
+}
+
+#define HIP_TRY(c, call)                                                              \
+  do {                                                                                \
+    hipError_t e__ = (call);                                                          \
+    if (e__ != hipSuccess)                                                            \
+      return fail((c), ADMM_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                  __FILE__, __LINE__);                                                \
+  } while (0)
+
+#define NCCL_TRY(c, call)                                                             \
+  do {                                                                                \
+    ncclResult_t r__ = (call);                                                        \
+    if (r__ != ncclSuccess)                                                           \
+      return fail((c), ADMM_E_COMM, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(r__), \
+                  __FILE__, __LINE__);                                                \
+  } while (0)
+
+template <typename T>
+int dev_alloc(admm_ctx *c, T **p, size_t n) {
+  void *q = nullptr;
+  hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
+  if (e != hipSuccess)
+    return fail(c, ADMM_E_NOMEM, "hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
+  c->allocs.push_back(q);
+  *p = (T *)q;
+  return ADMM_OK;
+}
+
+int grid_for(long long n, int block) {
+  long long g = (n + block - 1) / block;
+  return (int)std::max<long long>(1, std::min<long long>(g, 256 * 32));
+}
+
+int next_pow2(int k) {
+  int p = 2;
+  while (p < k) p <<= 1;
+  return p;
+}
+
+bool is_chain(const admm_ctx *c) { return c->d.solver == ADMM_SOLVER_CHAIN_MINSUM; }
+
+long long V_of(const admm_ctx *c) { return (long long)c->d.rows * c->d.cols; }
+
+// ------------------------------------------------------------------ chain launches
+
+struct SweepShape {
+  int KP, NS;
+};
+
+// Lane layout: when there are few chains, several lanes share a target label
+// (NS > 1) so that a wavefront's 64 lanes are all busy on one chain; when
+// chains are plentiful, narrow labels pack several chains into a wavefront.
+SweepShape pick_shape(int KP, long long nchains) {
+  const long long simd_slots = 256LL * 4 * 2;  // two wavefronts per SIMD
+  int NS = std::min(64 / KP, KP);
+  if (KP <= 16) {
+    // packing 64/KP chains per wavefront still fills the machine?
+    if (nchains / (64 / KP) >= simd_slots) NS = 1;
+  }
+  if (KP == 64) NS = 1;
+  return {KP, NS};
+}
+
+template <int KP, int NS, bool DUAL>
+void launch_sweep_t(const ChainArgs &a, int blocks, hipStream_t s) {
+  constexpr int U = (KP >= 64) ? 4 : 8;
+  hipLaunchKernelGGL((chain_sweep_kernel<KP, NS, U, DUAL>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+}
+
+template <bool DUAL>
+int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
+  const int CPW = 64 / (sh.KP * sh.NS);
+  int w = 0;
+  for (int i = 0; i < a.nseg; i++) {
+    a.wave_begin[i] = w;
+    w += (a.seg[i].nchains + CPW - 1) / CPW;
+  }
+  a.wave_begin[a.nseg] = w;
+  if (w == 0) return ADMM_OK;
+  const int blocks = (w + 3) / 4;
+  hipStream_t s = c->stream;
+#define SWEEP_CASE(kp, ns) \
+  if (sh.KP == kp && sh.NS == ns) { launch_sweep_t<kp, ns, DUAL>(a, blocks, s); goto launched; }
+  SWEEP_CASE(2, 1) SWEEP_CASE(2, 2)
+  SWEEP_CASE(4, 1) SWEEP_CASE(4, 4)
+  SWEEP_CASE(8, 1) SWEEP_CASE(8, 8)
+  SWEEP_CASE(16, 1) SWEEP_CASE(16, 4)
+  SWEEP_CASE(32, 2)
+  SWEEP_CASE(64, 1)
+#undef SWEEP_CASE
+  return fail(c, ADMM_E_ARG, "no sweep kernel for KP=%d NS=%d", sh.KP, sh.NS);
+launched:
+  HIP_TRY(c, hipGetLastError());
+  return ADMM_OK;
+}
+
+void fill_seg_rows(const admm_ctx *c, ChainSeg &s, bool dual) {
+  const admm_desc &d = c->d;
+  s.theta = c->th_r; s.lam = c->lam_r; s.m = c->m_r; s.x = c->xrow_r; s.bp = c->bp_r;
+  s.chain_min = dual ? c->d_chain_min : nullptr;
+  s.nchains = d.batch * c->st.nrows;
+  s.T = d.cols;
+  s.cpg = std::max(1, c->st.nrows);
+  s.gstride = (long long)c->st.nrows * d.cols;
+  s.cstride = d.cols;
+  s.sstride = 1;
+}
+
+void fill_seg_cols(const admm_ctx *c, ChainSeg &s, bool dual) {
+  const admm_desc &d = c->d;
+  s.theta = c->th_c; s.lam = c->lam_c; s.m = c->m_c; s.x = c->xcolT_c; s.bp = c->bp_c;
+  s.chain_min = dual ? c->d_chain_min + (long long)d.batch * c->st.nrows : nullptr;
+  s.nchains = d.batch * c->st.ncols;
+  s.T = d.rows;
+  s.cpg = std::max(1, c->st.ncols);
+  s.gstride = (long long)d.rows * c->st.ncols;
+  s.cstride = 1;
+  s.sstride = c->st.ncols;
+}
+
+int chain_sweep(admm_ctx *c, bool dual) {
+  ChainArgs a{};
+  a.nseg = 2;
+  fill_seg_rows(c, a.seg[0], dual);
+  fill_seg_cols(c, a.seg[1], dual);
+  a.k = c->d.k;
+  a.penalty = c->d.penalty;
+  a.rho = c->d.rho;
+  a.inv_k = c->inv_k;
+  a.Wt = dual ? c->d_Wsplit : c->d_Wt;
+  SweepShape sh = pick_shape(c->KP, (long long)a.seg[0].nchains + a.seg[1].nchains);
+  return dual ? launch_sweep<true>(c, a, sh) : launch_sweep<false>(c, a, sh);
+}
+
+int chain_consensus(admm_ctx *c, float *m, const int *xa, const int *xbT, int nr, int nc) {
+  if (nr <= 0 || nc <= 0) return ADMM_OK;
+  const int tr = (nr + 31) / 32, tc = (nc + 31) / 32;
+  const long long blocks = (long long)c->d.batch * tr * tc;
+  hipLaunchKernelGGL(chain_consensus_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, m, xa,
+                     xbT, nr, nc, c->d.k, c->inv_k, tc, tr * tc);
+  HIP_TRY(c, hipGetLastError());
+  return ADMM_OK;
+}
+
+// ------------------------------------------------------------------ edge helpers
+
+void build_incidence(admm_ctx *c) {
+  // Copies of every vertex in edge-list order: GetVerts' count (Grid.cpp:815-856)
+  // plus where the copies are, so the consensus can add them in that order.
+  c->h_inc_off.assign(c->V + 1, 0);
+  for (int i = 0; i < 2 * c->E; i++) c->h_inc_off[c->h_edges[i] + 1]++;
+  for (int v = 0; v < c->V; v++) c->h_inc_off[v + 1] += c->h_inc_off[v];
+  c->h_inc.assign(std::max(1, 2 * c->E), 0);
+  std::vector<int> fillp(c->h_inc_off.begin(), c->h_inc_off.end() - 1);
+  for (int i = 0; i < 2 * c->E; i++) c->h_inc[fillp[c->h_edges[i]]++] = i;
+}
+
+template <int KP>
+void launch_edge_t(const EdgeArgs &a, hipStream_t s) {
+  constexpr int GPB = (kEdgeBlock / 64) * (64 / KP);
+  const int blocks = (a.E + GPB - 1) / GPB;
+  hipLaunchKernelGGL((edge_solve_kernel<KP>), dim3(blocks), dim3(kEdgeBlock), 0, s, a);
+}
+
+int edge_compute(admm_ctx *c) {
+  if (c->E == 0) return ADMM_OK;
+  EdgeArgs a{};
+  a.E = c->E; a.V = c->V; a.k = c->d.k;
+  a.penalty = c->d.penalty; a.penaltyPrime = c->d.penalty_prime; a.rho = c->d.rho;
+  a.edgeList = c->d_edges;
+  a.mu_node = c->d_mu_node; a.pot_node = c->d_pot_node; a.lam_node = c->d_lam_node;
+  a.mu_edge = c->d_mu_edge; a.pot_edge = c->d_pot_edge; a.m_vert = c->d_m_vert;
+  switch (c->KP) {
+    case 2: launch_edge_t<2>(a, c->stream); break;
+    case 4: launch_edge_t<4>(a, c->stream); break;
+    case 8: launch_edge_t<8>(a, c->stream); break;
+    case 16: launch_edge_t<16>(a, c->stream); break;
+    case 32: launch_edge_t<32>(a, c->stream); break;
+    case 64: launch_edge_t<64>(a, c->stream); break;
+    default: return fail(c, ADMM_E_ARG, "edge solver supports k <= 64 (k=%d)", c->d.k);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return ADMM_OK;
+}
+
+int check_ctx(admm_ctx *c) {
+  if (!c) return ADMM_E_ARG;
+  hipError_t e = hipSetDevice(c->d.device);
+  if (e != hipSuccess) return fail(c, ADMM_E_HIP, "hipSetDevice(%d): %s", c->d.device, hipGetErrorString(e));
+  return ADMM_OK;
+}
+
+}  // namespace
+
+// ====================================================================== C ABI
+
+extern "C" {
+
+const char *admm_version(void) { return "admm_hip 0.1 (gfx950)"; }
+
+const char *admm_last_error(const admm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+void admm_partition(int n, int nranks, int rank, int *start, int *count) {
+  // Grid::PartitionByRow, Grid.cpp:377-390
+  const int base = n / nranks, extra = n % nranks;
+  int cnt, off;
+  if (rank < extra) { cnt = base + 1; off = rank * cnt; }
+  else { cnt = base; off = extra * (base + 1) + (rank - extra) * base; }
+  if (start) *start = off;
+  if (count) *count = cnt;
+}
+
+uint32_t admm_lcg_fill(uint32_t state, int64_t n, float *out) {
+  for (int64_t i = 0; i < n; i++) {
+    state = state * 1664525u + 1013904223u;
+    out[i] = (float)(state >> 8) / 16777216.0f;
+  }
+  return state;
+}
+
+int admm_grid_edges(int rows, int cols, int32_t *el) {
+  int e = 0;
+  for (int r = 0; r < rows; r++) {
+    for (int cidx = 0; cidx + 1 < cols; cidx++) { el[2 * e] = r * cols + cidx; el[2 * e + 1] = r * cols + cidx + 1; e++; }
+    if (r == rows - 1) break;
+    for (int cidx = 0; cidx < cols; cidx++) { el[2 * e] = r * cols + cidx; el[2 * e + 1] = (r + 1) * cols + cidx; e++; }
+  }
+  return e;
+}
+
+int admm_create(const admm_desc *desc, admm_ctx **out) {
+  if (!desc || !out) return fail(nullptr, ADMM_E_ARG, "null argument");
+  *out = nullptr;
+  const admm_desc &d = *desc;
+  if (d.k < 2) return fail(nullptr, ADMM_E_ARG, "k must be >= 2 (k=%d)", d.k);
+  if (d.k > 64) return fail(nullptr, ADMM_E_ARG, "k must be <= 64 (k=%d)", d.k);
+  if (d.batch < 1) return fail(nullptr, ADMM_E_ARG, "batch must be >= 1");
+  if (d.nranks < 1 || d.rank < 0 || d.rank >= d.nranks) return fail(nullptr, ADMM_E_ARG, "bad rank %d of %d", d.rank, d.nranks);
+  if (!(d.penalty > 0.f) || !(d.rho > 0.f)) return fail(nullptr, ADMM_E_ARG, "penalty and rho must be positive");
+  if (d.solver != ADMM_SOLVER_EDGE_BETHE && d.solver != ADMM_SOLVER_CHAIN_MINSUM)
+    return fail(nullptr, ADMM_E_ARG, "unknown solver %d", d.solver);
+  const bool graph = d.edge_list != nullptr;
+  if (!graph && (d.rows < 1 || d.cols < 1)) return fail(nullptr, ADMM_E_ARG, "rows and cols must be >= 1");
+  if (!graph && (long long)d.rows * d.cols * d.batch > (1LL << 31) - 1)
+    return fail(nullptr, ADMM_E_ARG, "more than 2^31-1 vertices");
+  if (d.solver == ADMM_SOLVER_CHAIN_MINSUM) {
+    if (graph) return fail(nullptr, ADMM_E_ARG, "the chain solver needs a grid, not an edge list");
+    if (d.nranks > 1 && d.batch != 1) return fail(nullptr, ADMM_E_ARG, "strips (nranks > 1) need batch == 1; shard a batch by grids instead");
+    if (d.exchange != ADMM_EXCHANGE_LABELS && d.exchange != ADMM_EXCHANGE_DENSE)
+      return fail(nullptr, ADMM_E_ARG, "unknown exchange mode %d", d.exchange);
+  } else {
+    if (d.nranks != 1) return fail(nullptr, ADMM_E_ARG, "the edge solver runs on one strip (nranks == 1)");
+    if (d.batch != 1) return fail(nullptr, ADMM_E_ARG, "the edge solver takes batch == 1");
+    if (!(d.penalty_prime > 0.f)) return fail(nullptr, ADMM_E_ARG, "penalty_prime must be positive");
+    if (graph && (d.num_vertices < 1 || d.num_edges < 0)) return fail(nullptr, ADMM_E_ARG, "bad graph sizes");
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(nullptr, ADMM_E_HIP, "no HIP device available");
+  if (d.device < 0 || d.device >= ndev) return fail(nullptr, ADMM_E_ARG, "device %d out of range (%d devices)", d.device, ndev);
+
+  admm_ctx *c = new admm_ctx;
+  c->d = d;
+  c->d.edge_list = nullptr;
+  c->KP = next_pow2(d.k);
+  c->inv_k = (float)(1.0 / (double)(float)d.k);  // Tree.cpp:25
+  int rc = ADMM_OK;
+  auto bail = [&](int code) { g_create_error = c->err; admm_destroy(c); return code; };
+  if (hipSetDevice(d.device) != hipSuccess) { c->err = "hipSetDevice failed"; return bail(ADMM_E_HIP); }
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(ADMM_E_HIP); }
+
+  if (d.solver == ADMM_SOLVER_EDGE_BETHE) {
+    if (graph) {
+      c->V = d.num_vertices; c->E = d.num_edges;
+      c->h_edges.assign(d.edge_list, d.edge_list + 2 * (size_t)c->E);
+      for (int v : c->h_edges) if (v < 0 || v >= c->V) { c->err = "edge list names a vertex outside [0, num_vertices)"; return bail(ADMM_E_ARG); }
+    } else {
+      c->V = d.rows * d.cols;
+      c->E = d.rows * (d.cols - 1) + d.cols * (d.rows - 1);
+      c->h_edges.resize(std::max(1, 2 * c->E));
+      admm_grid_edges(d.rows, d.cols, c->h_edges.data());
+    }
+    build_incidence(c);
+    const size_t E = c->E, V = c->V, k = d.k, k2 = k * k;
+    if ((rc = dev_alloc(c, &c->d_edges, 2 * E)) || (rc = dev_alloc(c, &c->d_inc_off, V + 1)) ||
+        (rc = dev_alloc(c, &c->d_inc, 2 * E)) || (rc = dev_alloc(c, &c->d_vert_pot, V * k)) ||
+        (rc = dev_alloc(c, &c->d_mu_node, E * 2 * k)) || (rc = dev_alloc(c, &c->d_pot_node, E * 2 * k)) ||
+        (rc = dev_alloc(c, &c->d_lam_node, E * 2 * k)) || (rc = dev_alloc(c, &c->d_mu_edge, E * k2)) ||
+        (rc = dev_alloc(c, &c->d_pot_edge, E * k2)) || (rc = dev_alloc(c, &c->d_m_vert, V * k)))
+      return bail(rc);
+    c->n_partial = 1024;
+    if ((rc = dev_alloc(c, &c->d_partial, (size_t)c->n_partial))) return bail(rc);
+    hipError_t e1 = hipMemcpy(c->d_edges, c->h_edges.data(), sizeof(int) * 2 * E, hipMemcpyHostToDevice);
+    hipError_t e2 = hipMemcpy(c->d_inc_off, c->h_inc_off.data(), sizeof(int) * (V + 1), hipMemcpyHostToDevice);
+    hipError_t e3 = hipMemcpy(c->d_inc, c->h_inc.data(), sizeof(int) * 2 * E, hipMemcpyHostToDevice);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { c->err = "copy of the edge list failed"; return bail(ADMM_E_HIP); }
+  } else {
+    admm_partition(d.rows, d.nranks, d.rank, &c->st.row0, &c->st.nrows);
+    admm_partition(d.cols, d.nranks, d.rank, &c->st.col0, &c->st.ncols);
+    const size_t k = d.k, B = d.batch;
+    const size_t nrow_nodes = B * (size_t)c->st.nrows * d.cols;
+    const size_t ncol_nodes = B * (size_t)d.rows * c->st.ncols;
+    const size_t Tp_r = ((size_t)d.cols + kChunk - 1) / kChunk * kChunk;
+    const size_t Tp_c = ((size_t)d.rows + kChunk - 1) / kChunk * kChunk;
+    if ((rc = dev_alloc(c, &c->th_r, nrow_nodes * k)) || (rc = dev_alloc(c, &c->lam_r, nrow_nodes * k)) ||
+        (rc = dev_alloc(c, &c->m_r, nrow_nodes * k)) || (rc = dev_alloc(c, &c->lam_c, ncol_nodes * k)) ||
+        (rc = dev_alloc(c, &c->xrow_r, nrow_nodes)) || (rc = dev_alloc(c, &c->xcolT_c, ncol_nodes)) ||
+        (rc = dev_alloc(c, &c->bp_r, B * c->st.nrows * Tp_r * c->KP + 16)) ||
+        (rc = dev_alloc(c, &c->bp_c, B * c->st.ncols * Tp_c * c->KP + 16)) ||
+        (rc = dev_alloc(c, &c->d_W, k * k)) || (rc = dev_alloc(c, &c->d_Wsplit, k * k)) ||
+        (rc = dev_alloc(c, &c->d_Wt, k * k)) ||
+        (rc = dev_alloc(c, &c->d_chain_min, B * ((size_t)c->st.nrows + c->st.ncols))))
+      return bail(rc);
+    if (d.nranks == 1) {
+      c->th_c = c->th_r; c->m_c = c->m_r; c->xrow_c = c->xrow_r; c->xcolT_r = c->xcolT_c;
+    } else {
+      if ((rc = dev_alloc(c, &c->th_c, ncol_nodes * k)) || (rc = dev_alloc(c, &c->m_c, ncol_nodes * k)) ||
+          (rc = dev_alloc(c, &c->xrow_c, ncol_nodes)) || (rc = dev_alloc(c, &c->xcolT_r, nrow_nodes)) ||
+          (rc = dev_alloc(c, &c->sendbuf, nrow_nodes + ncol_nodes)))
+        return bail(rc);
+    }
+    c->n_partial = 2 * (int)std::max<size_t>(B * d.rows, 1) + 2;
+    if ((rc = dev_alloc(c, &c->d_partial, (size_t)c->n_partial * 2))) return bail(rc);
+  }
+  *out = c;
+  return ADMM_OK;
+}
+
+int admm_destroy(admm_ctx *c) {
+  if (!c) return ADMM_OK;
+  hipSetDevice(c->d.device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+  for (auto &pr : c->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+  for (void *p : c->allocs) hipFree(p);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+  return ADMM_OK;
+}
+
+int admm_strip_info(const admm_ctx *c, int *row0, int *nrows, int *col0, int *ncols) {
+  if (!c) return ADMM_E_ARG;
+  if (row0) *row0 = c->st.row0;
+  if (nrows) *nrows = c->st.nrows;
+  if (col0) *col0 = c->st.col0;
+  if (ncols) *ncols = c->st.ncols;
+  return ADMM_OK;
+}
+
+int admm_upload_unaries(admm_ctx *c, const float *unary) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!unary) return fail(c, ADMM_E_ARG, "null unary array");
+  const size_t k = c->d.k;
+  if (!is_chain(c)) {
+    HIP_TRY(c, hipMemcpyAsync(c->d_vert_pot, unary, sizeof(float) * (size_t)c->V * k, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  } else {
+    const admm_desc &d = c->d;
+    const size_t Vg = (size_t)d.rows * d.cols;
+    for (int g = 0; g < d.batch; g++) {
+      // whole rows of the strip are contiguous in the caller's array
+      const float *src = unary + (g * Vg + (size_t)c->st.row0 * d.cols) * k;
+      float *dst = c->th_r + (size_t)g * c->st.nrows * d.cols * k;
+      HIP_TRY(c, hipMemcpyAsync(dst, src, sizeof(float) * (size_t)c->st.nrows * d.cols * k, hipMemcpyHostToDevice, c->stream));
+    }
+    if (d.nranks > 1) {
+      // column strip: a pitched copy, rows x (ncols*k floats) out of rows x (cols*k)
+      HIP_TRY(c, hipMemcpy2DAsync(c->th_c, sizeof(float) * c->st.ncols * k,
+                                  unary + (size_t)c->st.col0 * k, sizeof(float) * d.cols * k,
+                                  sizeof(float) * c->st.ncols * k, d.rows, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  c->have_unary = true;
+  c->inited = false;
+  return ADMM_OK;
+}
+
+int admm_upload_pairwise(admm_ctx *c, const float *table, int per_edge) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!table) return fail(c, ADMM_E_ARG, "null pairwise table");
+  const size_t k2 = (size_t)c->d.k * c->d.k;
+  if (is_chain(c)) {
+    if (per_edge) return fail(c, ADMM_E_ARG, "the chain solver takes one shared k x k table (per_edge = 0)");
+    HIP_TRY(c, hipMemcpy(c->d_W, table, sizeof(float) * k2, hipMemcpyHostToDevice));
+  } else {
+    const size_t n = per_edge ? k2 * (size_t)c->E : k2;
+    if (!c->d_edge_pot || c->pair_per_edge != (per_edge ? 1 : 0)) {
+      if ((rc = dev_alloc(c, &c->d_edge_pot, n))) return rc;
+    }
+    c->pair_per_edge = per_edge ? 1 : 0;
+    HIP_TRY(c, hipMemcpy(c->d_edge_pot, table, sizeof(float) * n, hipMemcpyHostToDevice));
+  }
+  c->have_pair = true;
+  c->inited = false;
+  return ADMM_OK;
+}
+
+// In-place element-wise set-up kernels of the chain solver.
+namespace {
+__global__ void chain_init_theta_kernel(float *__restrict__ th, long long n, float rho) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    // Grid.cpp:1478-1487 with two copies, then Grid.cpp:953-956
+    const float t = th[i];
+    float s = 0.0f;
+    s += t;
+    s += t;
+    s = s / 2;
+    th[i] = s / (rho * 2);
+  }
+}
+__global__ void chain_init_w_kernel(float *Wsplit, float *Wt, const float *W, int n, float rho) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float ws = W[i] / rho;  // Grid.cpp:975-976
+    Wsplit[i] = ws;
+    Wt[i] = rho * ws;  // Tree.cpp:99
+  }
+}
+}  // namespace
+
+int admm_init(admm_ctx *c) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!c->have_unary || !c->have_pair) return fail(c, ADMM_E_STATE, "upload unaries and the pairwise table before admm_init");
+  const admm_desc &d = c->d;
+  hipStream_t s = c->stream;
+  if (!is_chain(c)) {
+    const long long E = c->E, V = c->V, k = d.k, k2 = k * k;
+    const float inv_k2 = (float)(1.0 / (double)(float)(d.k * d.k));
+    if (E > 0) {
+      hipLaunchKernelGGL(edge_init_node_kernel, dim3(grid_for(E * 2 * k, 256)), dim3(256), 0, s, c->d_pot_node,
+                         c->d_mu_node, c->d_lam_node, c->d_vert_pot, c->d_edges, c->d_inc_off, (int)E, (int)k, d.rho, c->inv_k);
+      hipLaunchKernelGGL(edge_init_edge_kernel, dim3(grid_for(E * k2, 256)), dim3(256), 0, s, c->d_pot_edge,
+                         c->d_mu_edge, c->d_edge_pot, c->pair_per_edge, E * k2, (int)k2, d.rho, inv_k2);
+    }
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(V * k, 256)), dim3(256), 0, s, c->d_m_vert, V * k, c->inv_k);
+    HIP_TRY(c, hipGetLastError());
+  } else {
+    if (c->inited) return fail(c, ADMM_E_STATE, "admm_init was already called; upload the unaries again to restart");
+    const long long k = d.k;
+    const long long nrow = (long long)d.batch * c->st.nrows * d.cols, ncol = (long long)d.batch * d.rows * c->st.ncols;
+    hipLaunchKernelGGL(chain_init_theta_kernel, dim3(grid_for(nrow * k, 256)), dim3(256), 0, s, c->th_r, nrow * k, d.rho);
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(nrow * k, 256)), dim3(256), 0, s, c->m_r, nrow * k, c->inv_k);
+    HIP_TRY(c, hipMemsetAsync(c->lam_r, 0, sizeof(float) * nrow * k, s));
+    HIP_TRY(c, hipMemsetAsync(c->lam_c, 0, sizeof(float) * ncol * k, s));
+    hipLaunchKernelGGL(fill_int_kernel, dim3(grid_for(nrow, 256)), dim3(256), 0, s, c->xrow_r, nrow, -1);
+    hipLaunchKernelGGL(fill_int_kernel, dim3(grid_for(ncol, 256)), dim3(256), 0, s, c->xcolT_c, ncol, -1);
+    if (d.nranks > 1) {
+      hipLaunchKernelGGL(chain_init_theta_kernel, dim3(grid_for(ncol * k, 256)), dim3(256), 0, s, c->th_c, ncol * k, d.rho);
+      hipLaunchKernelGGL(fill_kernel, dim3(grid_for(ncol * k, 256)), dim3(256), 0, s, c->m_c, ncol * k, c->inv_k);
+      hipLaunchKernelGGL(fill_int_kernel, dim3(grid_for(nrow, 256)), dim3(256), 0, s, c->xcolT_r, nrow, -1);
+      hipLaunchKernelGGL(fill_int_kernel, dim3(grid_for(ncol, 256)), dim3(256), 0, s, c->xrow_c, ncol, -1);
+    }
+    hipLaunchKernelGGL(chain_init_w_kernel, dim3((d.k * d.k + 255) / 256), dim3(256), 0, s, c->d_Wsplit, c->d_Wt, c->d_W, d.k * d.k, d.rho);
+    HIP_TRY(c, hipGetLastError());
+  }
+  HIP_TRY(c, hipStreamSynchronize(s));
+  c->inited = true;
+  return ADMM_OK;
+}
+
+int admm_compute(admm_ctx *c) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!c->inited) return fail(c, ADMM_E_STATE, "admm_compute before admm_init");
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c->prof) {
+    if (c->prof_used == c->prof_events.size()) {
+      hipEvent_t a, b;
+      HIP_TRY(c, hipEventCreate(&a));
+      HIP_TRY(c, hipEventCreate(&b));
+      c->prof_events.push_back({a, b});
+    }
+    e0 = c->prof_events[c->prof_used].first;
+    e1 = c->prof_events[c->prof_used].second;
+    c->prof_used++;
+    HIP_TRY(c, hipEventRecord(e0, c->stream));
+  }
+  rc = is_chain(c) ? chain_sweep(c, false) : edge_compute(c);
+  if (rc) return rc;
+  if (c->prof) HIP_TRY(c, hipEventRecord(e1, c->stream));
+  return ADMM_OK;
+}
+
+int admm_communicate(admm_ctx *c) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!c->inited) return fail(c, ADMM_E_STATE, "admm_communicate before admm_init");
+  const admm_desc &d = c->d;
+  if (d.nranks == 1) return ADMM_OK;  // no neighbours: Grid.cpp:1643 loops zero times
+  if (!c->comm) return fail(c, ADMM_E_COMM, "admm_comm_init must be called before admm_communicate when nranks > 1");
+  hipStream_t s = c->stream;
+  const int G = d.nranks;
+  const int nr = c->st.nrows, nc = c->st.ncols;
+  // Pack, per peer h: my row-chain labels on h's columns (nr x nc_h) and my
+  // column-chain labels on h's rows (nc x nr_h).  Both arrive contiguous on
+  // the other side: xrow_c is [rows][nc] and xcolT_r is [cols][nr].
+  std::vector<long long> off_a(G + 1, 0), off_b(G + 1, 0);
+  for (int h = 0; h < G; h++) {
+    int c0h, nch, r0h, nrh;
+    admm_partition(d.cols, G, h, &c0h, &nch);
+    admm_partition(d.rows, G, h, &r0h, &nrh);
+    off_a[h + 1] = off_a[h] + (long long)nr * nch;
+    off_b[h + 1] = off_b[h] + (long long)nc * nrh;
+  }
+  int *send_a = c->sendbuf, *send_b = c->sendbuf + off_a[G];
+  for (int h = 0; h < G; h++) {
+    int c0h, nch, r0h, nrh;
+    admm_partition(d.cols, G, h, &c0h, &nch);
+    admm_partition(d.rows, G, h, &r0h, &nrh);
+    if (nr > 0 && nch > 0)
+      hipLaunchKernelGGL(label_block_copy_kernel, dim3(grid_for((long long)nr * nch, 256)), dim3(256), 0, s,
+                         send_a + off_a[h], (long long)nch, c->xrow_r + c0h, (long long)d.cols, nr, nch);
+    if (nc > 0 && nrh > 0)
+      hipLaunchKernelGGL(label_block_copy_kernel, dim3(grid_for((long long)nc * nrh, 256)), dim3(256), 0, s,
+                         send_b + off_b[h], (long long)nrh, c->xcolT_c + r0h, (long long)d.rows, nc, nrh);
+  }
+  HIP_TRY(c, hipGetLastError());
+  NCCL_TRY(c, ncclGroupStart());
+  for (int h = 0; h < G; h++) {
+    int c0h, nch, r0h, nrh;
+    admm_partition(d.cols, G, h, &c0h, &nch);
+    admm_partition(d.rows, G, h, &r0h, &nrh);
+    // a: row-chain labels.  I send (nr x nc_h); I receive h's rows on my columns (nr_h x nc).
+    if ((long long)nr * nch > 0) NCCL_TRY(c, ncclSend(send_a + off_a[h], (size_t)nr * nch, ncclInt32, h, c->comm, s));
+    if ((long long)nrh * nc > 0) NCCL_TRY(c, ncclRecv(c->xrow_c + (long long)r0h * nc, (size_t)nrh * nc, ncclInt32, h, c->comm, s));
+    // b: column-chain labels.  I send (nc x nr_h); I receive h's columns on my rows (nc_h x nr).
+    if ((long long)nc * nrh > 0) NCCL_TRY(c, ncclSend(send_b + off_b[h], (size_t)nc * nrh, ncclInt32, h, c->comm, s));
+    if ((long long)nch * nr > 0) NCCL_TRY(c, ncclRecv(c->xcolT_r + (long long)c0h * nr, (size_t)nch * nr, ncclInt32, h, c->comm, s));
+  }
+  NCCL_TRY(c, ncclGroupEnd());
+  return ADMM_OK;
+}
+
+int admm_update(admm_ctx *c) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!c->inited) return fail(c, ADMM_E_STATE, "admm_update before admm_init");
+  const admm_desc &d = c->d;
+  if (!is_chain(c)) {
+    const long long n = (long long)c->V * d.k;
+    hipLaunchKernelGGL(edge_consensus_kernel, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d_m_vert,
+                       c->d_mu_node, c->d_inc_off, c->d_inc, c->V, d.k);
+    HIP_TRY(c, hipGetLastError());
+    return ADMM_OK;
+  }
+  if ((rc = chain_consensus(c, c->m_r, c->xrow_r, c->xcolT_r, c->st.nrows, d.cols))) return rc;
+  if (d.nranks > 1 && (rc = chain_consensus(c, c->m_c, c->xrow_c, c->xcolT_c, d.rows, c->st.ncols))) return rc;
+  return ADMM_OK;
+}
+
+static int chain_obj_partials(admm_ctx *c, double *primal, double *linear) {
+  const admm_desc &d = c->d;
+  hipStream_t s = c->stream;
+  double p = 0.0, l = 0.0;
+  std::vector<double> h;
+  auto run = [&](const float *th, const int *xa, const int *xbT, int nr, int nc, int mode) -> int {
+    const int rows_total = d.batch * nr;
+    if (rows_total <= 0 || nc <= 0) return ADMM_OK;
+    if (2 * rows_total > c->n_partial * 2) return fail(c, ADMM_E_STATE, "objective scratch too small");
+    hipLaunchKernelGGL(chain_objective_kernel, dim3((rows_total + 3) / 4), dim3(256), 0, s, c->d_partial, th,
+                       c->d_Wsplit, xa, xbT, nr, nc, d.k, rows_total, mode);
+    HIP_TRY(c, hipGetLastError());
+    h.resize(2 * (size_t)rows_total);
+    HIP_TRY(c, hipMemcpyAsync(h.data(), c->d_partial, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    for (int i = 0; i < rows_total; i++) { p += h[2 * i]; l += h[2 * i + 1]; }
+    return ADMM_OK;
+  };
+  int rc;
+  if (d.nranks == 1) {
+    if ((rc = run(c->th_r, c->xrow_r, c->xcolT_r, d.rows, d.cols, 3))) return rc;
+  } else {
+    if ((rc = run(c->th_r, c->xrow_r, c->xcolT_r, c->st.nrows, d.cols, 1))) return rc;
+    if ((rc = run(c->th_c, c->xrow_c, c->xcolT_c, d.rows, c->st.ncols, 2))) return rc;
+  }
+  if (primal) *primal = p * d.rho;
+  if (linear) *linear = l * d.rho;
+  return ADMM_OK;
+}
+
+int admm_linear_objective(admm_ctx *c, double *obj) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!c->inited) return fail(c, ADMM_E_STATE, "objective before admm_init");
+  if (!obj) return fail(c, ADMM_E_ARG, "null output");
+  if (is_chain(c)) return chain_obj_partials(c, nullptr, obj);
+  const long long nn = (long long)c->E * 2 * c->d.k, ne = (long long)c->E * c->d.k * c->d.k;
+  const int blocks = std::min(c->n_partial, grid_for(std::max(nn, ne), 256));
+  hipLaunchKernelGGL(edge_objective_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_partial, c->d_pot_node,
+                     c->d_mu_node, nn, c->d_pot_edge, c->d_mu_edge, ne);
+  HIP_TRY(c, hipGetLastError());
+  std::vector<double> h(blocks);
+  HIP_TRY(c, hipMemcpyAsync(h.data(), c->d_partial, sizeof(double) * blocks, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  double s = 0.0;
+  for (double v : h) s += v;
+  *obj = s * c->d.rho;
+  return ADMM_OK;
+}
+
+int admm_objective(admm_ctx *c, double *primal, double *dual) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!c->inited) return fail(c, ADMM_E_STATE, "objective before admm_init");
+  if (!is_chain(c)) {
+    if (dual) *dual = std::nan("");
+    return primal ? admm_linear_objective(c, primal) : ADMM_OK;
+  }
+  if (primal && (rc = chain_obj_partials(c, primal, nullptr))) return rc;
+  if (dual) {
+    if ((rc = chain_sweep(c, true))) return rc;
+    const size_t n = (size_t)c->d.batch * ((size_t)c->st.nrows + c->st.ncols);
+    std::vector<float> h(n);
+    HIP_TRY(c, hipMemcpyAsync(h.data(), c->d_chain_min, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double s = 0.0;
+    for (float v : h) s += (double)v;
+    *dual = s * c->d.rho;
+  }
+  return ADMM_OK;
+}
+
+int admm_synchronize(admm_ctx *c) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ADMM_OK;
+}
+
+int admm_finalize(admm_ctx *c) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+  return ADMM_OK;
+}
+
+namespace {
+__global__ void chain_decode_kernel(int *__restrict__ out, const int *__restrict__ xa,
+                                    const int *__restrict__ xbT, int nr, int nc, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long g = i / ((long long)nr * nc), rem = i % ((long long)nr * nc);
+    const long long r = rem / nc, cc = rem % nc;
+    out[i] = chain_decode(xa[i], xbT[g * nr * nc + cc * nr + r]);
+  }
+}
+__global__ void transpose_int_kernel(int *__restrict__ out, const int *__restrict__ in, int nr, int nc,
+                                     long long total) {
+  // in: [g][nc][nr] -> out: [g][nr][nc]
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long g = i / ((long long)nr * nc), rem = i % ((long long)nr * nc);
+    const long long r = rem / nc, cc = rem % nc;
+    out[i] = in[g * nr * nc + cc * nr + r];
+  }
+}
+}  // namespace
+
+int admm_download_labels(admm_ctx *c, int32_t *labels) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!is_chain(c)) return fail(c, ADMM_E_STATE, "the edge solver decodes no labels");
+  if (!c->inited) return fail(c, ADMM_E_STATE, "download before admm_init");
+  if (!labels) return fail(c, ADMM_E_ARG, "null output");
+  const long long total = (long long)c->d.batch * c->st.nrows * c->d.cols;
+  if (total == 0) return ADMM_OK;
+  int *tmp = nullptr;
+  HIP_TRY(c, hipMalloc((void **)&tmp, sizeof(int) * total));
+  hipLaunchKernelGGL(chain_decode_kernel, dim3(grid_for(total, 256)), dim3(256), 0, c->stream, tmp, c->xrow_r,
+                     c->xcolT_r, c->st.nrows, c->d.cols, total);
+  hipError_t e = hipMemcpyAsync(labels, tmp, sizeof(int) * total, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(tmp);
+  HIP_TRY(c, e);
+  return ADMM_OK;
+}
+
+int admm_download_consensus(admm_ctx *c, float *out) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!c->inited) return fail(c, ADMM_E_STATE, "download before admm_init");
+  if (!out) return fail(c, ADMM_E_ARG, "null output");
+  const float *src = is_chain(c) ? c->m_r : c->d_m_vert;
+  const size_t n = is_chain(c) ? (size_t)c->d.batch * c->st.nrows * c->d.cols * c->d.k : (size_t)c->V * c->d.k;
+  HIP_TRY(c, hipMemcpyAsync(out, src, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ADMM_OK;
+}
+
+size_t admm_state_size(const admm_ctx *c, int which) {
+  if (!c) return 0;
+  const size_t k = c->d.k;
+  if (!is_chain(c)) {
+    if (which >= 0 && which <= 3) return (size_t)c->E * 2 * k;
+    if (which == 4 || which == 5) return (size_t)c->E * k * k;
+    return 0;
+  }
+  const size_t nrow = (size_t)c->d.batch * c->st.nrows * c->d.cols, ncol = (size_t)c->d.batch * c->d.rows * c->st.ncols;
+  switch (which) {
+    case 10: case 12: return nrow * k;
+    case 11: return ncol * k;
+    case 13: return nrow;
+    case 14: return ncol;
+  }
+  return 0;
+}
+
+int admm_download_state(admm_ctx *c, int which, float *out) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!c->inited) return fail(c, ADMM_E_STATE, "download before admm_init");
+  if (!out) return fail(c, ADMM_E_ARG, "null output");
+  const size_t n = admm_state_size(c, which);
+  if (n == 0) return fail(c, ADMM_E_ARG, "unknown state id %d for this solver", which);
+  const void *src = nullptr;
+  void *tmp = nullptr;
+  if (!is_chain(c)) {
+    switch (which) {
+      case 0: src = c->d_mu_node; break;
+      case 1: src = c->d_pot_node; break;
+      case 3: src = c->d_lam_node; break;
+      case 4: src = c->d_mu_edge; break;
+      case 5: src = c->d_pot_edge; break;
+      case 2:
+        HIP_TRY(c, hipMalloc(&tmp, sizeof(float) * n));
+        hipLaunchKernelGGL(edge_gather_m_kernel, dim3(grid_for((long long)n, 256)), dim3(256), 0, c->stream,
+                           (float *)tmp, c->d_m_vert, c->d_edges, c->E, c->d.k);
+        src = tmp;
+        break;
+    }
+  } else {
+    switch (which) {
+      case 10: src = c->lam_r; break;
+      case 11: src = c->lam_c; break;
+      case 12: src = c->th_r; break;
+      case 13: src = c->xrow_r; break;
+      case 14:
+        // stored chain-major ([col][row]); hand it out as [row][col]
+        HIP_TRY(c, hipMalloc(&tmp, sizeof(int) * n));
+        hipLaunchKernelGGL(transpose_int_kernel, dim3(grid_for((long long)n, 256)), dim3(256), 0, c->stream,
+                           (int *)tmp, c->xcolT_c, c->d.rows, c->st.ncols, (long long)n);
+        src = tmp;
+        break;
+    }
+  }
+  hipError_t e = hipMemcpyAsync(out, src, 4 * n, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (tmp) hipFree(tmp);
+  HIP_TRY(c, e);
+  return ADMM_OK;
+}
+
+int admm_comm_get_unique_id(void *id) {
+  if (!id) return ADMM_E_ARG;
+  static_assert(sizeof(ncclUniqueId) <= ADMM_COMM_ID_BYTES, "id buffer too small");
+  ncclUniqueId u;
+  ncclResult_t r = ncclGetUniqueId(&u);
+  if (r != ncclSuccess) return fail(nullptr, ADMM_E_COMM, "ncclGetUniqueId: %s", ncclGetErrorString(r));
+  memset(id, 0, ADMM_COMM_ID_BYTES);
+  memcpy(id, &u, sizeof(u));
+  return ADMM_OK;
+}
+
+int admm_comm_init(admm_ctx *c, const void *id) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!id) return fail(c, ADMM_E_ARG, "null id");
+  if (c->comm) return fail(c, ADMM_E_STATE, "communicator already initialised");
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof(u));
+  NCCL_TRY(c, ncclCommInitRank(&c->comm, c->d.nranks, u, c->d.rank));
+  return ADMM_OK;
+}
+
+int admm_profile_reset(admm_ctx *c, int enable) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->prof = enable != 0;
+  c->prof_used = 0;
+  return ADMM_OK;
+}
+
+int admm_profile_read(admm_ctx *c, double *ms_avg, int *launches) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  double tot = 0.0;
+  for (size_t i = 0; i < c->prof_used; i++) {
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->prof_events[i].first, c->prof_events[i].second));
+    tot += ms;
+  }
+  if (ms_avg) *ms_avg = c->prof_used ? tot / (double)c->prof_used : 0.0;
+  if (launches) *launches = (int)c->prof_used;
+  return ADMM_OK;
+}
+
+}  // extern "C"

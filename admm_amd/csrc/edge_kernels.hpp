@@ -1,0 +1,271 @@
+// Edge (Bethe sum-product) solver kernels for gfx950: the reference's own
+// subproblem, one tree per edge (Tree.h:20-51).  A group of KP lanes owns one
+// edge; lane i holds entry i of the node vectors and walks row / column i of
+// the k x k table, so every running sum is accumulated in the same order as
+// the reference's scalar loops.  log / exp are evaluated in binary64 and
+// rounded to binary32 exactly where the reference stores into a float.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace admm {
+
+struct EdgeArgs {
+  int E, V, k;
+  float penalty, penaltyPrime, rho;
+  const int *edgeList;    // [E][2]
+  float *mu_node;         // [E][2k]  x_mu_node
+  const float *pot_node;  // [E][2k]  x_potential_node
+  float *lam_node;        // [E][2k]  lambda_node
+  float *mu_edge;         // [E][k*k] x_mu_edge
+  const float *pot_edge;  // [E][k*k] x_potential_edge
+  const float *m_vert;    // [V][k]   consensus (what edge_mu_node holds)
+};
+
+__device__ __forceinline__ void edge_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+constexpr int kEdgeBlock = 256;
+
+// Tree.cpp:64-274 for one edge per KP-lane group.
+template <int KP>
+__global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p) {
+  constexpr int EPW = 64 / KP;
+  constexpr int GPB = (kEdgeBlock / 64) * EPW;  // edge groups per workgroup
+  constexpr int LD = KP + 1;                    // padded row of the k x k scratch
+  __shared__ float s_ep[GPB][KP * LD];
+  __shared__ float s_np[GPB][2 * KP];
+  __shared__ float s_lmu[GPB][2 * KP];
+  __shared__ float s_buf[GPB][KP];
+  __shared__ float s_m12[GPB][KP];
+  __shared__ float s_m21[GPB][KP];
+
+  const int grp = threadIdx.x / KP;
+  const int i = threadIdx.x % KP;
+  const long long e_raw = (long long)blockIdx.x * GPB + grp;
+  const bool evalid = e_raw < p.E;
+  const long long e = evalid ? e_raw : p.E - 1;
+  const int k = p.k, k2 = k * k;
+  const bool iv = i < k;
+  const bool wr = evalid && iv;
+  const float EPS = 0.00000000000000001;  // Tree.h:15
+  const float pen = p.penalty, pp = p.penaltyPrime, rho = p.rho;
+
+  float *ep = s_ep[grp];
+  float *np = s_np[grp];
+  float *lmu = s_lmu[grp];
+  float *buf = s_buf[grp];
+
+  // node vectors: UpdateLambda, AdjustPotentials, UpdateMu, node derivatives
+  // and node potentials (Tree.cpp:64-73, 84-86, 48-51, 120-122, 141-143, 157-160)
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int v = p.edgeList[2 * e + h];
+    float mu = 1.0f, m = 1.0f, lam = 0.0f, pot = 0.0f;
+    if (iv) {
+      mu = p.mu_node[e * 2 * k + h * k + i];
+      m = p.m_vert[(long long)v * k + i];
+      lam = p.lam_node[e * 2 * k + h * k + i];
+      pot = p.pot_node[e * 2 * k + h * k + i];
+    }
+    lam = lam + pen * (mu - m);
+    if (wr) p.lam_node[e * 2 * k + h * k + i] = lam;
+    const float xnode = rho * (pot + lam) - pen * (m - mu);
+    const float muc = ((double)mu <= 0.0) ? EPS : mu;
+    const float lv = (float)log((double)muc);
+    const float nd = (float)(-1.0 - (double)lv);
+    float val = xnode + pp * nd;
+    val = val / pp;
+    np[h * KP + i] = 0.0f - val;
+    lmu[h * KP + i] = lv;
+  }
+  edge_lds_fence();
+
+  // edge derivatives and potentials (Tree.cpp:123-133, 144-150, 98-99, 169-172)
+  for (int a = 0; a < k; a++) {
+    float mue = 1.0f, pe = 0.0f;
+    if (iv) {
+      mue = p.mu_edge[e * k2 + a * k + i];
+      pe = p.pot_edge[e * k2 + a * k + i];
+    }
+    const float muec = ((double)mue <= 0.0) ? EPS : mue;
+    float ed = (float)(((double)lmu[a] - log((double)muec)) + 1.0);
+    ed = ed + lmu[KP + i];
+    const float xe = rho * pe;
+    float val = xe + pp * ed;
+    val = val / pp;
+    ep[a * LD + i] = 0.0f - val;
+  }
+  edge_lds_fence();
+
+  // message 1 -> 2 (Tree.cpp:191-205): lane b sums over a
+  float acc = 0.0f;
+  for (int a = 0; a < k; a++) {
+    const float c = ep[a * LD + i] + np[a];
+    acc = (float)((double)acc + exp((double)c));
+  }
+  buf[i] = acc;
+  edge_lds_fence();
+  float sum = 0.0f;
+  for (int j = 0; j < k; j++) sum += buf[j];
+  s_m12[grp][i] = acc / sum;
+  edge_lds_fence();
+
+  // message 2 -> 1 (Tree.cpp:212-229): lane a sums over b
+  acc = 0.0f;
+  for (int b = 0; b < k; b++) {
+    const float c = ep[i * LD + b] + np[KP + b];
+    acc = (float)((double)acc + exp((double)c));
+  }
+  buf[i] = acc;
+  edge_lds_fence();
+  sum = 0.0f;
+  for (int j = 0; j < k; j++) sum += buf[j];
+  s_m21[grp][i] = acc / sum;
+  edge_lds_fence();
+
+  // node marginals (Tree.cpp:236-254)
+  float t1 = (float)(exp((double)np[i]) * (double)s_m21[grp][i]);
+  buf[i] = t1;
+  edge_lds_fence();
+  sum = 0.0f;
+  for (int j = 0; j < k; j++) sum += buf[j];
+  const float mu1 = t1 / sum;
+  edge_lds_fence();
+  float t2 = (float)(exp((double)np[KP + i]) * (double)s_m12[grp][i]);
+  buf[i] = t2;
+  edge_lds_fence();
+  sum = 0.0f;
+  for (int j = 0; j < k; j++) sum += buf[j];
+  const float mu2 = t2 / sum;
+  if (wr) {
+    p.mu_node[e * 2 * k + i] = mu1;
+    p.mu_node[e * 2 * k + k + i] = mu2;
+  }
+
+  // edge marginal (Tree.cpp:256-273): lane a owns row a
+  acc = 0.0f;
+  for (int b = 0; b < k; b++) {
+    float q = ep[i * LD + b] + np[i];
+    q = q + np[KP + b];
+    const float ex = (float)exp((double)q);
+    ep[i * LD + b] = ex;
+    acc = acc + ex;
+  }
+  for (int b = 0; b < k; b++) {
+    const float ex = ep[i * LD + b];
+    ep[i * LD + b] = (acc != 0.0f) ? (mu1 * ex / acc) : 0.0f;
+  }
+  edge_lds_fence();
+  if (wr)
+    for (int a = 0; a < k; a++) p.mu_edge[e * k2 + a * k + i] = ep[a * LD + i];
+}
+
+// Consensus (Grid.cpp:144-148 + Tree.cpp:244,253 + Grid.cpp:163-181): the
+// copies of vertex v are summed in edge-list order, as the serial loop of
+// Grid::Compute adds them, then divided by the copy count.  inc holds, per
+// vertex, the positions (2*edge + endpoint) of its copies in ascending order.
+__global__ void edge_consensus_kernel(float *__restrict__ m_vert, const float *__restrict__ mu_node,
+                                      const int *__restrict__ inc_off, const int *__restrict__ inc,
+                                      int V, int k) {
+  const long long total = (long long)V * k;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(idx / k), l = (int)(idx % k);
+    const int b = inc_off[v], en = inc_off[v + 1];
+    float s = 0.0f;
+    for (int q = b; q < en; q++) s += mu_node[(long long)inc[q] * k + l];
+    const int cnt = en - b;
+    m_vert[idx] = s / cnt;
+  }
+}
+
+// Initial split of the unaries (Grid.cpp:1478-1487, 952-956): theta_v added
+// once per copy, divided by the copy count, then by rho * count.
+__global__ void edge_init_node_kernel(float *__restrict__ pot_node, float *__restrict__ mu_node,
+                                      float *__restrict__ lam_node,
+                                      const float *__restrict__ vert_pot,
+                                      const int *__restrict__ edgeList,
+                                      const int *__restrict__ inc_off, int E, int k, float rho,
+                                      float inv_k) {
+  const long long total = (long long)E * 2 * k;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const long long ep = idx / k;  // 2*edge + endpoint
+    const int l = (int)(idx % k);
+    const int v = edgeList[ep];
+    const int cnt = inc_off[v + 1] - inc_off[v];
+    const float th = vert_pot[(long long)v * k + l];
+    float s = 0.0f;
+    for (int q = 0; q < cnt; q++) s += th;
+    s = s / cnt;
+    pot_node[idx] = s / (rho * cnt);
+    mu_node[idx] = inv_k;
+    lam_node[idx] = 0.0f;
+  }
+}
+
+__global__ void edge_init_edge_kernel(float *__restrict__ pot_edge, float *__restrict__ mu_edge,
+                                      const float *__restrict__ edge_pot, int per_edge,
+                                      long long total, int k2, float rho, float inv_k2) {
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const float w = per_edge ? edge_pot[idx] : edge_pot[idx % k2];
+    pot_edge[idx] = w / rho;  // Grid.cpp:975-976
+    mu_edge[idx] = inv_k2;    // Grid.cpp:977
+  }
+}
+
+__global__ void fill_kernel(float *__restrict__ p, long long n, float v) {
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n;
+       idx += (long long)gridDim.x * blockDim.x)
+    p[idx] = v;
+}
+
+__global__ void fill_int_kernel(int *__restrict__ p, long long n, int v) {
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n;
+       idx += (long long)gridDim.x * blockDim.x)
+    p[idx] = v;
+}
+
+// Gather of the consensus into per-edge layout (what Grid::Update copies into
+// edge_mu_node, Grid.cpp:188-192); used when that state is downloaded.
+__global__ void edge_gather_m_kernel(float *__restrict__ m_node, const float *__restrict__ m_vert,
+                                     const int *__restrict__ edgeList, int E, int k) {
+  const long long total = (long long)E * 2 * k;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const long long ep = idx / k;
+    m_node[idx] = m_vert[(long long)edgeList[ep] * k + idx % k];
+  }
+}
+
+// Linear objective (Grid.cpp:1665-1680): binary32 products accumulated in
+// binary64.  Each workgroup reduces a contiguous slice of the concatenated
+// [node | edge] product streams and writes one partial.
+__global__ __launch_bounds__(256) void edge_objective_kernel(
+    double *__restrict__ partial, const float *__restrict__ pot_node,
+    const float *__restrict__ mu_node, long long n_node, const float *__restrict__ pot_edge,
+    const float *__restrict__ mu_edge, long long n_edge) {
+  __shared__ double s_red[4];
+  double acc = 0.0;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n_node; i += stride) {
+    const float pr = pot_node[i] * mu_node[i];
+    acc += (double)pr;
+  }
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n_edge; i += stride) {
+    const float pr = pot_edge[i] * mu_edge[i];
+    acc += (double)pr;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+}  // namespace admm

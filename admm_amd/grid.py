@@ -1,0 +1,244 @@
+"""Host-side mirror of the reference's driver API (class Grid, Grid.h:98-137).
+
+The method names and their order of use are the reference's (admm.cpp:41-101):
+SetPartitioner, SetPenalties, SetGlobalInfo, Load / Generate, InitOptimization,
+then per iteration Compute, Communicate, Update, ComputeLinearObj, and finally
+FinalizeOptimization.  Every method forwards to the C ABI of libadmm_hip.so;
+nothing is computed in Python.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (AdmmDesc, AdmmError, EXCHANGE_DENSE, EXCHANGE_LABELS,
+                   SOLVER_CHAIN_MINSUM, SOLVER_EDGE_BETHE, lib)
+
+# enum Partitioner (Grid.h:21)
+ROW, COL, BLOCK, EDGE = 0, 1, 2, 3
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+
+
+def _f(a):
+    return a.ctypes.data_as(_fp)
+
+
+def partition(n, nranks, rank):
+    """Grid::PartitionByRow's split (Grid.cpp:377-390): (start, count)."""
+    s, c = C.c_int(), C.c_int()
+    lib.admm_partition(n, nranks, rank, C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def lcg_fill(state, n):
+    out = np.empty(int(n), dtype=np.float32)
+    st = lib.admm_lcg_fill(C.c_uint32(state & 0xFFFFFFFF), int(n), _f(out))
+    return out, st
+
+
+def grid_edges(rows, cols):
+    E = rows * (cols - 1) + cols * (rows - 1)
+    el = np.empty(2 * max(E, 1), dtype=np.int32)
+    n = lib.admm_grid_edges(rows, cols, el.ctypes.data_as(_ip))
+    assert n == E
+    return el[:2 * E].copy()
+
+
+def pairwise_table(kind, k, lcg_state=None):
+    """The pairwise cost tables of the benchmark configurations."""
+    a = np.arange(k, dtype=np.float32)[:, None]
+    b = np.arange(k, dtype=np.float32)[None, :]
+    if kind == "potts":
+        return (0.5 * (a != b)).astype(np.float32)
+    if kind == "trunc_linear":
+        return (np.minimum(np.abs(a - b), 4.0) * 0.25).astype(np.float32)
+    if kind == "dense":
+        w, _ = lcg_fill(lcg_state, k * k)
+        return w.reshape(k, k).copy()
+    raise ValueError("unknown pairwise kind %r" % (kind,))
+
+
+class Grid:
+    """One strip of an ADMM MAP-inference problem on one GPU."""
+
+    def __init__(self, rank=0, nprocs=1, device=0):
+        self._rank, self._nprocs, self._device = int(rank), int(nprocs), int(device)
+        self.part = EDGE
+        self.penalty, self.penaltyPrime, self.rhoEdge = 0.1, 0.5, 1.0  # Grid.cpp:79-80
+        self.rows = self.cols = self.k = 0
+        self.batch = 1
+        self.exchange = EXCHANGE_LABELS
+        self._edge_list = None
+        self._num_vertices = 0
+        self._unary = None
+        self._pairwise = None
+        self._per_edge = False
+        self._h = None
+
+    # ---- configuration (Grid.h:98-111) ----
+    def GetRank(self):
+        return self._rank
+
+    def GetNprocs(self):
+        return self._nprocs
+
+    def SetPartitioner(self, part):
+        """EDGE: the reference's solver (one tree per edge).  ROW: row and
+        column chains over row / column strips."""
+        if part not in (ROW, EDGE):
+            raise ValueError("no implementation for this partitioner")  # Grid.cpp:1153-1158
+        self.part = part
+
+    def SetPenalties(self, p, pp):
+        self.penalty, self.penaltyPrime = float(p), float(pp)
+
+    def SetRhoEdge(self, rho):
+        self.rhoEdge = float(rho)
+
+    def SetGlobalInfo(self, rows, cols, vert_potential_size, edge_potential_size=None, batch=1):
+        if edge_potential_size is not None and edge_potential_size != vert_potential_size ** 2:
+            raise ValueError("numEdgePotentials must be numVertPotentials squared")
+        self.rows, self.cols, self.k, self.batch = int(rows), int(cols), int(vert_potential_size), int(batch)
+
+    def SetGraph(self, num_vertices, edge_list):
+        """Arbitrary edge list (what Grid::Load reads from a file, Grid.cpp:476-494)."""
+        self._edge_list = np.ascontiguousarray(edge_list, dtype=np.int32).reshape(-1)
+        self._num_vertices = int(num_vertices)
+
+    # ---- data ----
+    def Load(self, unary, pairwise, per_edge=False):
+        """Potentials as Grid holds them after the loader's sign flip
+        (Grid.cpp:547-560): costs.  unary [batch*rows*cols, k]; pairwise either
+        one k x k table or [E, k*k]."""
+        self._unary = np.ascontiguousarray(unary, dtype=np.float32).reshape(-1)
+        self._pairwise = np.ascontiguousarray(pairwise, dtype=np.float32).reshape(-1)
+        self._per_edge = bool(per_edge)
+
+    def Generate(self, seed=1234, pairwise="potts"):
+        """Synthetic potentials: LCG unaries in [0,1) drawn node-major, grid g
+        of a batch seeded with seed+g, and a named pairwise table."""
+        n = self.rows * self.cols * self.k
+        parts, st = [], None
+        for g in range(self.batch):
+            u, st_g = lcg_fill(seed + g, n)
+            parts.append(u)
+            if g == 0:
+                st = st_g
+        self.Load(np.concatenate(parts), pairwise_table(pairwise, self.k, st))
+
+    # ---- optimisation (admm.cpp:73-101) ----
+    def InitOptimization(self):
+        if self._unary is None:
+            raise AdmmError(-2, "Load or Generate before InitOptimization")
+        d = AdmmDesc()
+        d.rows, d.cols, d.k, d.batch = self.rows, self.cols, self.k, self.batch
+        d.solver = SOLVER_EDGE_BETHE if self.part == EDGE else SOLVER_CHAIN_MINSUM
+        d.penalty, d.penalty_prime, d.rho = self.penalty, self.penaltyPrime, self.rhoEdge
+        d.device, d.rank, d.nranks = self._device, self._rank, self._nprocs
+        d.exchange = self.exchange
+        if self._edge_list is not None:
+            d.edge_list = self._edge_list.ctypes.data_as(_ip)
+            d.num_vertices = self._num_vertices
+            d.num_edges = self._edge_list.size // 2
+        h = C.c_void_p()
+        rc = lib.admm_create(C.byref(d), C.byref(h))
+        if rc != 0:
+            raise AdmmError(rc, (lib.admm_last_error(None) or b"").decode())
+        self._h = h
+        self._ck(lib.admm_upload_unaries(self._h, _f(self._unary)))
+        self._ck(lib.admm_upload_pairwise(self._h, _f(self._pairwise), 1 if self._per_edge else 0))
+        self._ck(lib.admm_init(self._h))
+
+    def CommInit(self, unique_id):
+        buf = C.create_string_buffer(bytes(unique_id), _lib.COMM_ID_BYTES)
+        self._ck(lib.admm_comm_init(self._h, buf))
+
+    def Compute(self):
+        self._ck(lib.admm_compute(self._h))
+
+    def Communicate(self):
+        self._ck(lib.admm_communicate(self._h))
+
+    def Update(self):
+        self._ck(lib.admm_update(self._h))
+
+    def ComputeLinearObj(self):
+        v = C.c_double()
+        self._ck(lib.admm_linear_objective(self._h, C.byref(v)))
+        return v.value
+
+    def Objective(self, dual=True):
+        p, d = C.c_double(), C.c_double(float("nan"))
+        self._ck(lib.admm_objective(self._h, C.byref(p), C.byref(d) if dual else None))
+        return p.value, d.value
+
+    def Synchronize(self):
+        self._ck(lib.admm_synchronize(self._h))
+
+    def FinalizeOptimization(self):
+        if self._h:
+            self._ck(lib.admm_finalize(self._h))
+
+    # ---- results ----
+    def StripInfo(self):
+        v = [C.c_int() for _ in range(4)]
+        self._ck(lib.admm_strip_info(self._h, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
+    def Labels(self):
+        _, nrows, _, _ = self.StripInfo()
+        out = np.empty((self.batch, nrows, self.cols), dtype=np.int32)
+        self._ck(lib.admm_download_labels(self._h, out.ctypes.data_as(_ip)))
+        return out[0] if self.batch == 1 else out
+
+    def Consensus(self):
+        if self.part == EDGE:
+            V = self._num_vertices if self._edge_list is not None else self.rows * self.cols
+            out = np.empty((V, self.k), dtype=np.float32)
+        else:
+            _, nrows, _, _ = self.StripInfo()
+            out = np.empty((self.batch * nrows * self.cols, self.k), dtype=np.float32)
+        self._ck(lib.admm_download_consensus(self._h, _f(out)))
+        return out
+
+    def State(self, which):
+        n = lib.admm_state_size(self._h, which)
+        if n == 0:
+            raise AdmmError(-1, "unknown state id %d" % which)
+        is_int = which in (13, 14)
+        out = np.empty(n, dtype=np.int32 if is_int else np.float32)
+        self._ck(lib.admm_download_state(self._h, which, C.cast(out.ctypes.data, _fp)))
+        return out
+
+    def ProfileReset(self, enable=True):
+        self._ck(lib.admm_profile_reset(self._h, 1 if enable else 0))
+
+    def ProfileRead(self):
+        ms, n = C.c_double(), C.c_int()
+        self._ck(lib.admm_profile_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if self._h:
+            lib.admm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise AdmmError(rc, (lib.admm_last_error(self._h) or b"").decode())
+
+
+def unique_id():
+    buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+    rc = lib.admm_comm_get_unique_id(buf)
+    if rc != 0:
+        raise AdmmError(rc, (lib.admm_last_error(None) or b"").decode())
+    return bytes(buf.raw)

@@ -1,0 +1,167 @@
+/*
+ * admm_hip.h -- C ABI of libadmm_hip.so, the MI355X implementation of the ADMM
+ * MAP-inference hot path of xiaocai00/ADMM.
+ *
+ * The reference has no FFI layer: its driver (admm.cpp:41-101) calls methods
+ * of class Grid, and Grid::Compute hands every tree to class Edge
+ * (Grid.cpp:1400-1410, Tree.h:47-50).  The entry points below sit on that
+ * seam.  Each one names the reference code it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative ADMM_E_* code on
+ *     failure; admm_last_error() gives the message (the reference has no
+ *     error returns at all, Grid.cpp:26-30 only prints);
+ *   - the caller owns every host buffer, the context owns all device memory;
+ *   - one context per GPU; calls on one context are not thread-safe, calls on
+ *     different contexts are independent;
+ *   - compute / communicate / update are stream-ordered on the context's own
+ *     HIP stream and return without waiting; admm_synchronize(), the
+ *     objective calls and the download calls wait for the stream;
+ *   - all arithmetic that the reference does in binary32 is done in binary32
+ *     without fused multiply-add.
+ */
+#ifndef ADMM_HIP_H_
+#define ADMM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADMM_OK 0
+#define ADMM_E_ARG (-1)     /* bad argument or unsupported size            */
+#define ADMM_E_STATE (-2)   /* call out of order (e.g. compute before init) */
+#define ADMM_E_HIP (-3)     /* a HIP runtime call failed                    */
+#define ADMM_E_COMM (-4)    /* an RCCL call failed / communicator missing   */
+#define ADMM_E_NOMEM (-5)
+
+/* Subproblem solver. */
+#define ADMM_SOLVER_EDGE_BETHE 0   /* one tree per edge, Tree.cpp:112-274      */
+#define ADMM_SOLVER_CHAIN_MINSUM 1 /* row + column chains, min-sum (Viterbi)   */
+
+/* What crosses GPUs between the row and the column chains (chain solver). */
+#define ADMM_EXCHANGE_LABELS 0 /* int32 labels; consensus rebuilt on both sides */
+#define ADMM_EXCHANGE_DENSE 1  /* one-hot marginals as float k-vectors          */
+
+typedef struct admm_ctx admm_ctx;
+
+/* Problem and placement.  Replaces Grid::SetGlobalInfo (Grid.cpp:96-116),
+ * Grid::SetPenalties (Grid.h:98), Grid::SetRhoEdge (Grid.h:111) and
+ * Grid::SetPartitioner (Grid.h:110). */
+typedef struct admm_desc {
+  int32_t rows;          /* numGlobalRows                                     */
+  int32_t cols;          /* numGlobalCols                                     */
+  int32_t k;             /* numVertPotentials; chain solver: 2..64            */
+  int32_t batch;         /* independent grids of this shape (>= 1)            */
+  int32_t solver;        /* ADMM_SOLVER_*                                     */
+  float penalty;         /* admm.cpp:44, first argument                       */
+  float penalty_prime;   /* admm.cpp:44, second argument (edge solver only)   */
+  float rho;             /* rhoEdge, always 1.0 in the reference              */
+  int32_t device;        /* HIP device ordinal                                */
+  int32_t rank;          /* this context's strip, 0 <= rank < nranks          */
+  int32_t nranks;        /* strips; > 1 needs the chain solver and batch == 1 */
+  int32_t exchange;      /* ADMM_EXCHANGE_*                                   */
+  /* Edge solver on an arbitrary graph (the reference accepts any edge list,
+   * Grid.cpp:476-494).  NULL: the grid's own edge list in the order of
+   * Grid::Generate (Grid.cpp:581-615). */
+  const int32_t *edge_list;  /* 2 * num_edges vertex ids                      */
+  int32_t num_vertices;
+  int32_t num_edges;
+} admm_desc;
+
+/* Grid::Grid + Grid::Load's allocations (Grid.cpp:456-460, 1607-1613). */
+int admm_create(const admm_desc *desc, admm_ctx **out);
+/* Grid::~Grid (Grid.cpp:121-142). */
+int admm_destroy(admm_ctx *ctx);
+/* Message of the last failure on ctx (or, with NULL, of the last failed
+ * admm_create on this thread). */
+const char *admm_last_error(const admm_ctx *ctx);
+
+/* Unary costs, node-major [batch][rows*cols][k] (graph mode: [V][k]): the
+ * values Grid holds after the loader's sign flip (Grid.cpp:510-523, 547-553).
+ * Always the whole problem; a strip context keeps its own share. */
+int admm_upload_unaries(admm_ctx *ctx, const float *unary);
+/* Pairwise costs after the sign flip (Grid.cpp:529-543, 554-560).
+ * per_edge = 1: [num_edges][k*k] in edge-list order (edge solver);
+ * per_edge = 0: one k*k table W[a*k+b], a = label of the edge's first vertex,
+ * shared by every edge (required by the chain solver). */
+int admm_upload_pairwise(admm_ctx *ctx, const float *table, int per_edge);
+
+/* Grid::InitOptimization + InitTree (Grid.cpp:1474-1491, 934-980) and the
+ * copy counts of GetVerts / InitNeighborsByEdge (Grid.cpp:815-856, 309-319). */
+int admm_init(admm_ctx *ctx);
+/* Grid::Compute (Grid.cpp:1394-1412): dual update, potential adjust and the
+ * subproblem of every tree (Tree.cpp:64-274). */
+int admm_compute(admm_ctx *ctx);
+/* Grid::Communicate (Grid.cpp:1509-1526, 1639-1663).  One strip: nothing to
+ * exchange.  Several strips: RCCL all-to-all of the chain labels. */
+int admm_communicate(admm_ctx *ctx);
+/* Grid::Update + UpdateMuArrAfterComm (Grid.cpp:186-193, 163-181). */
+int admm_update(admm_ctx *ctx);
+/* Grid::ComputeLinearObj (Grid.cpp:1665-1680): this strip's share of
+ * rho * sum over trees of <theta, mu>; the caller sums over strips as
+ * admm.cpp:95 does. */
+int admm_linear_objective(admm_ctx *ctx, double *obj);
+/* Chain solver: this strip's share of the energy of the decoded labelling
+ * (primal) and of the sum of chain minima under theta + lambda (dual).
+ * Either pointer may be NULL.  Edge solver: primal = the linear objective,
+ * dual = NaN.  No counterpart in the reference, which decodes no labels. */
+int admm_objective(admm_ctx *ctx, double *primal, double *dual);
+/* Waits for everything queued on the context's stream. */
+int admm_synchronize(admm_ctx *ctx);
+/* Grid::FinalizeOptimization (Grid.cpp:1414-1416): releases the communicator. */
+int admm_finalize(admm_ctx *ctx);
+
+/* Results.  Labels: decoded labelling of this strip's rows,
+ * [batch][strip rows][cols] (chain solver).  Consensus: vertMuArr after
+ * Update, [batch][strip rows * cols][k] (graph mode [V][k]). */
+int admm_download_labels(admm_ctx *ctx, int32_t *labels);
+int admm_download_consensus(admm_ctx *ctx, float *consensus);
+
+/* Solver state for parity tests.  Edge solver (members of class Edge,
+ * Tree.h:26-35): 0 x_mu_node, 1 x_potential_node, 2 edge_mu_node,
+ * 3 lambda_node ([E][2k]); 4 x_mu_edge, 5 x_potential_edge ([E][k*k]).
+ * Chain solver: 10 lambda of the row chains [strip rows][cols][k],
+ * 11 lambda of the column chains [rows][strip cols][k], 12 per-copy unary
+ * share [strip rows][cols][k]; 13 row-chain labels [strip rows][cols],
+ * 14 column-chain labels [rows][strip cols] (int32, -1 before the first
+ * Compute; pass an int32 buffer cast to float*). */
+int admm_download_state(admm_ctx *ctx, int which, float *out);
+/* Number of elements admm_download_state writes for `which` (0 if unknown). */
+size_t admm_state_size(const admm_ctx *ctx, int which);
+
+/* Strip partition (Grid::PartitionByRow, Grid.cpp:377-390): n items over
+ * nranks, the remainder going to the lowest ranks.  Pure host arithmetic. */
+void admm_partition(int n, int nranks, int rank, int *start, int *count);
+/* This context's strips. */
+int admm_strip_info(const admm_ctx *ctx, int *row0, int *nrows, int *col0, int *ncols);
+
+/* Multi-GPU bootstrap.  Rank 0 fills a 128-byte RCCL id, the caller ships it
+ * to every rank by its own means (the reference's is MPI_Init), and every
+ * rank calls admm_comm_init before the first admm_communicate. */
+#define ADMM_COMM_ID_BYTES 128
+int admm_comm_get_unique_id(void *id);
+int admm_comm_init(admm_ctx *ctx, const void *id);
+
+/* Synthetic inputs (Grid::Generate, Grid.cpp:631-645, with a reproducible
+ * generator instead of rand()): 32-bit LCG s = s*1664525 + 1013904223,
+ * u = (float)(s >> 8) / 2^24.  Fills out[0..n) and returns the new state. */
+uint32_t admm_lcg_fill(uint32_t state, int64_t n, float *out);
+/* Edge list of a rows x cols grid in Grid::Generate's order; returns E. */
+int admm_grid_edges(int rows, int cols, int32_t *edge_list);
+
+/* Device-side timing of the solver kernels: average duration in milliseconds
+ * of the Compute launches since the last reset, measured with HIP events on
+ * the context's stream, and how many launches that covers. */
+int admm_profile_reset(admm_ctx *ctx, int enable);
+int admm_profile_read(admm_ctx *ctx, double *compute_ms_avg, int *launches);
+
+/* Library version string. */
+const char *admm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADMM_HIP_H_ */
