@@ -19,7 +19,7 @@ COMM_ID_BYTES = 128
 EXPORTS = [
     "admm_create", "admm_destroy", "admm_last_error", "admm_upload_unaries",
     "admm_upload_pairwise", "admm_init", "admm_compute", "admm_communicate", "admm_update",
-    "admm_linear_objective", "admm_objective", "admm_synchronize", "admm_finalize",
+    "admm_linear_objective", "admm_objective", "admm_objective_enqueue", "admm_objective_read", "admm_synchronize", "admm_finalize",
     "admm_download_labels", "admm_download_consensus", "admm_download_state",
     "admm_state_size", "admm_partition", "admm_strip_info", "admm_comm_get_unique_id",
     "admm_comm_init", "admm_lcg_fill", "admm_grid_edges", "admm_profile_reset",
@@ -62,6 +62,8 @@ def _load():
         "admm_update": (C.c_int, [vp]),
         "admm_linear_objective": (C.c_int, [vp, dp]),
         "admm_objective": (C.c_int, [vp, dp, dp]),
+        "admm_objective_enqueue": (C.c_int, [vp, C.c_int]),
+        "admm_objective_read": (C.c_int, [vp, C.c_int, C.c_int, dp, dp]),
         "admm_synchronize": (C.c_int, [vp]),
         "admm_finalize": (C.c_int, [vp]),
         "admm_download_labels": (C.c_int, [vp, ip]),

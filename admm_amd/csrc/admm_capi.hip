@@ -45,6 +45,8 @@ struct admm_ctx {
   float *d_mu_edge = nullptr, *d_pot_edge = nullptr, *d_m_vert = nullptr;
   double *d_partial = nullptr;
   int n_partial = 0;
+  double *d_obj_slots = nullptr;  // [n_obj_slots][2] (primal, linear) queued objective values
+  int n_obj_slots = 0;
 
   // ---- chain solver ----
   Strip st;
@@ -123,8 +125,6 @@ int next_pow2(int k) {
 }
 
 bool is_chain(const admm_ctx *c) { return c->d.solver == ADMM_SOLVER_CHAIN_MINSUM; }
-
-long long V_of(const admm_ctx *c) { return (long long)c->d.rows * c->d.cols; }
 
 // ------------------------------------------------------------------ chain launches
 
@@ -404,8 +404,10 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
           (rc = dev_alloc(c, &c->sendbuf, nrow_nodes + ncol_nodes)))
         return bail(rc);
     }
-    c->n_partial = 2 * (int)std::max<size_t>(B * d.rows, 1) + 2;
+    c->n_partial = (int)std::max<size_t>(B * d.rows, 1);
     if ((rc = dev_alloc(c, &c->d_partial, (size_t)c->n_partial * 2))) return bail(rc);
+    c->n_obj_slots = 4096;
+    if ((rc = dev_alloc(c, &c->d_obj_slots, (size_t)c->n_obj_slots * 2))) return bail(rc);
   }
   *out = c;
   return ADMM_OK;
@@ -413,12 +415,12 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
 
 int admm_destroy(admm_ctx *c) {
   if (!c) return ADMM_OK;
-  hipSetDevice(c->d.device);
-  if (c->stream) hipStreamSynchronize(c->stream);
+  (void)hipSetDevice(c->d.device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
-  for (auto &pr : c->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
-  for (void *p : c->allocs) hipFree(p);
-  if (c->stream) hipStreamDestroy(c->stream);
+  for (auto &pr : c->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (void *p : c->allocs) (void)hipFree(p);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return ADMM_OK;
 }
@@ -638,22 +640,42 @@ int admm_update(admm_ctx *c) {
   return ADMM_OK;
 }
 
-static int chain_obj_partials(admm_ctx *c, double *primal, double *linear) {
+namespace {
+// Sums per-row partial pairs into dst[0] (+=primal) and dst[1] (+=linear).
+__global__ __launch_bounds__(256) void objective_reduce_kernel(double *__restrict__ dst,
+                                                               const double *__restrict__ part,
+                                                               int n, int accumulate) {
+  __shared__ double s_red[2][4];
+  double p = 0.0, l = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) { p += part[2 * i]; l += part[2 * i + 1]; }
+  p = wave_sum(p);
+  l = wave_sum(l);
+  if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = p; s_red[1][threadIdx.x >> 6] = l; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double ps = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    const double ls = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+    dst[0] = (accumulate ? dst[0] : 0.0) + ps;
+    dst[1] = (accumulate ? dst[1] : 0.0) + ls;
+  }
+}
+}  // namespace
+
+// Queues the chain objective kernels; dst (device, 2 doubles) receives the
+// primal and the linear sums of this strip, not yet scaled by rho.
+static int chain_obj_enqueue(admm_ctx *c, double *dst) {
   const admm_desc &d = c->d;
   hipStream_t s = c->stream;
-  double p = 0.0, l = 0.0;
-  std::vector<double> h;
+  int pass = 0;
   auto run = [&](const float *th, const int *xa, const int *xbT, int nr, int nc, int mode) -> int {
     const int rows_total = d.batch * nr;
     if (rows_total <= 0 || nc <= 0) return ADMM_OK;
-    if (2 * rows_total > c->n_partial * 2) return fail(c, ADMM_E_STATE, "objective scratch too small");
+    if (rows_total > c->n_partial) return fail(c, ADMM_E_STATE, "objective scratch too small");
     hipLaunchKernelGGL(chain_objective_kernel, dim3((rows_total + 3) / 4), dim3(256), 0, s, c->d_partial, th,
                        c->d_Wsplit, xa, xbT, nr, nc, d.k, rows_total, mode);
+    hipLaunchKernelGGL(objective_reduce_kernel, dim3(1), dim3(256), 0, s, dst, c->d_partial, rows_total, pass);
     HIP_TRY(c, hipGetLastError());
-    h.resize(2 * (size_t)rows_total);
-    HIP_TRY(c, hipMemcpyAsync(h.data(), c->d_partial, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    for (int i = 0; i < rows_total; i++) { p += h[2 * i]; l += h[2 * i + 1]; }
+    pass++;
     return ADMM_OK;
   };
   int rc;
@@ -663,8 +685,18 @@ static int chain_obj_partials(admm_ctx *c, double *primal, double *linear) {
     if ((rc = run(c->th_r, c->xrow_r, c->xcolT_r, c->st.nrows, d.cols, 1))) return rc;
     if ((rc = run(c->th_c, c->xrow_c, c->xcolT_c, d.rows, c->st.ncols, 2))) return rc;
   }
-  if (primal) *primal = p * d.rho;
-  if (linear) *linear = l * d.rho;
+  if (pass == 0) HIP_TRY(c, hipMemsetAsync(dst, 0, 2 * sizeof(double), s));
+  return ADMM_OK;
+}
+
+static int chain_obj_partials(admm_ctx *c, double *primal, double *linear) {
+  int rc = chain_obj_enqueue(c, c->d_obj_slots);
+  if (rc) return rc;
+  double h[2];
+  HIP_TRY(c, hipMemcpyAsync(h, c->d_obj_slots, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (primal) *primal = h[0] * c->d.rho;
+  if (linear) *linear = h[1] * c->d.rho;
   return ADMM_OK;
 }
 
@@ -706,6 +738,30 @@ int admm_objective(admm_ctx *c, double *primal, double *dual) {
     double s = 0.0;
     for (float v : h) s += (double)v;
     *dual = s * c->d.rho;
+  }
+  return ADMM_OK;
+}
+
+int admm_objective_enqueue(admm_ctx *c, int slot) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!c->inited) return fail(c, ADMM_E_STATE, "objective before admm_init");
+  if (!is_chain(c)) return fail(c, ADMM_E_STATE, "queued objectives are a chain-solver feature");
+  if (slot < 1 || slot >= c->n_obj_slots) return fail(c, ADMM_E_ARG, "slot must be in [1, %d)", c->n_obj_slots);
+  return chain_obj_enqueue(c, c->d_obj_slots + 2 * (size_t)slot);
+}
+
+int admm_objective_read(admm_ctx *c, int slot, int n, double *primal, double *linear) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!is_chain(c)) return fail(c, ADMM_E_STATE, "queued objectives are a chain-solver feature");
+  if (slot < 1 || n < 0 || slot + n > c->n_obj_slots) return fail(c, ADMM_E_ARG, "slot range out of bounds");
+  std::vector<double> h(2 * (size_t)n);
+  HIP_TRY(c, hipMemcpyAsync(h.data(), c->d_obj_slots + 2 * (size_t)slot, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n; i++) {
+    if (primal) primal[i] = h[2 * i] * c->d.rho;
+    if (linear) linear[i] = h[2 * i + 1] * c->d.rho;
   }
   return ADMM_OK;
 }
@@ -761,7 +817,7 @@ int admm_download_labels(admm_ctx *c, int32_t *labels) {
                      c->xcolT_r, c->st.nrows, c->d.cols, total);
   hipError_t e = hipMemcpyAsync(labels, tmp, sizeof(int) * total, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  hipFree(tmp);
+  (void)hipFree(tmp);
   HIP_TRY(c, e);
   return ADMM_OK;
 }
@@ -836,7 +892,7 @@ int admm_download_state(admm_ctx *c, int which, float *out) {
   }
   hipError_t e = hipMemcpyAsync(out, src, 4 * n, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  if (tmp) hipFree(tmp);
+  if (tmp) (void)hipFree(tmp);
   HIP_TRY(c, e);
   return ADMM_OK;
 }

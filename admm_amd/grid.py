@@ -174,6 +174,16 @@ class Grid:
         self._ck(lib.admm_objective(self._h, C.byref(p), C.byref(d) if dual else None))
         return p.value, d.value
 
+    def ObjectiveEnqueue(self, slot):
+        self._ck(lib.admm_objective_enqueue(self._h, int(slot)))
+
+    def ObjectiveRead(self, slot, n):
+        p = np.empty(n, dtype=np.float64)
+        l = np.empty(n, dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        self._ck(lib.admm_objective_read(self._h, int(slot), int(n), p.ctypes.data_as(dp), l.ctypes.data_as(dp)))
+        return p, l
+
     def Synchronize(self):
         self._ck(lib.admm_synchronize(self._h))
 

@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Benchmark of the ADMM hot path: row/column chain min-sum on a 2048 x 2048 grid, k = 32.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step is one ADMM iteration as the reference's driver loop runs it
+(admm.cpp:78-100): Compute, Communicate, Update and the per-iteration linear
+objective.  The objective values are left in device slots and read after the
+timed region, so the loop never waits for the host.  With N > 1 the same grid is
+cut into N row strips / column strips (strong scaling), one process per GPU, and
+the chain labels cross GPUs through RCCL inside admm_communicate.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# The HIP library comes first so that the process uses one HIP / RCCL runtime,
+# the one the library was built against.
+import admm_amd as A  # noqa: E402
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, datasheet
+
+WORKLOADS = {
+    # name: rows, cols, k, batch, pairwise
+    "2048x2048_k32_potts": (2048, 2048, 32, 1, "potts"),
+    "512x512_k16_trunc_linear": (512, 512, 16, 1, "trunc_linear"),
+    "1024x1024_k64_dense": (1024, 1024, 64, 1, "dense"),
+    "256x(256x256)_k8_potts": (256, 256, 8, 256, "potts"),
+    "64x64_k4_potts": (64, 64, 4, 1, "potts"),
+}
+
+
+def bytes_per_iteration(V, k):
+    """Algorithmic HBM bytes of one ADMM iteration: V * (36 k + 24)."""
+    return V * (36 * k + 24)
+
+
+def sweep_bytes(V, k):
+    """Share of the chain sweep kernel: theta read twice (8k), both lambda
+    arrays read and written (16k), consensus read twice (8k), both label arrays
+    read and written (16)."""
+    return V * (32 * k + 16)
+
+
+def cpu_baseline(rows, cols, k, pairwise, seed, seconds_budget=25.0):
+    """The CPU restatement of the same iteration, timed on the host cores."""
+    from oracle import oracle as O
+    threads = min(16, os.cpu_count() or 1)
+    O.set_threads(threads)
+    un, W = O.synth_problem(rows, cols, k, seed, pairwise)
+    o = O.ChainOracle(rows, cols, k, un, W)
+    o.init()
+    t0 = time.perf_counter()
+    its = 0
+    while True:
+        o.compute()
+        o.update()
+        o.objective(dual=False)
+        its += 1
+        if time.perf_counter() - t0 > seconds_budget * 0.5 or its >= 20:
+            break
+    dt = time.perf_counter() - t0
+    return {
+        "value": its / dt, "unit": "it/s", "cores": threads, "kind": "port",
+        "sample": "%d full ADMM iterations (compute + update + linear objective) of the %dx%d k=%d grid, "
+                  "oracle/admm_oracle.c with one chain per OpenMP thread" % (its, rows, cols, k),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="2048x2048_k32_potts", choices=sorted(WORKLOADS))
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", default="labels", choices=["labels", "dense"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
+        args.gpus = world
+    if args.steps + args.warmup >= 4000:
+        sys.exit("steps + warmup must stay below 4000 (objective slots)")
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # control plane only (gloo): id broadcast, barrier, max
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    rows, cols, k, batch, pairwise = WORKLOADS[args.workload]
+    my_batch = batch
+    nprocs_for_grid = world
+    if batch > 1 and world > 1:
+        # independent grids: shard the batch, no exchange
+        b0, my_batch = A.partition(batch, world, rank)
+        nprocs_for_grid = 1
+    else:
+        b0 = 0
+
+    g = A.Grid(rank=rank if nprocs_for_grid > 1 else 0, nprocs=nprocs_for_grid, device=local_rank)
+    g.SetPartitioner(A.ROW)
+    g.SetPenalties(0.5, 1.0)  # admm.cpp:44
+    g.SetGlobalInfo(rows, cols, k, batch=my_batch)
+    g.exchange = 0 if args.exchange == "labels" else 1
+    g.Generate(seed=args.seed + b0, pairwise=pairwise)
+    g.InitOptimization()
+    g._unary = None  # the host copy is no longer needed
+    if nprocs_for_grid > 1:
+        ids = [A.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        g.CommInit(ids[0])
+
+    def barrier():
+        g.Synchronize()
+        if dist is not None:
+            dist.barrier()
+        g.Synchronize()
+
+    def step(i):
+        g.Compute()
+        g.Communicate()
+        g.Update()
+        g.ObjectiveEnqueue(1 + i)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    g.ProfileReset(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    g.Synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    sweep_ms, launches = g.ProfileRead()
+    g.ProfileReset(False)
+    primal, linear = g.ObjectiveRead(1 + args.warmup, args.steps)
+    _, dual = g.Objective(dual=True)
+    last = np.array([primal[-1], linear[-1], dual], dtype=np.float64)
+    if dist is not None:
+        import torch
+        tt = torch.from_numpy(last)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)  # admm.cpp:95
+        sm = torch.tensor([sweep_ms], dtype=torch.float64)
+        dist.all_reduce(sm, op=dist.ReduceOp.MAX)
+        sweep_ms = float(sm[0])
+
+    V = rows * cols * batch
+    it_per_s = args.steps / elapsed
+    b_it = bytes_per_iteration(V, k)
+    sweep_b = sweep_bytes(V, k) / world
+    achieved = sweep_b / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "admm_iterations_per_sec",
+            "value": it_per_s,
+            "unit": "it/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak" if (batch > 1) else "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": args.workload, "rows": rows, "cols": cols, "k": k, "batch": batch,
+                "pairwise": pairwise, "solver": "chain_minsum", "penalty": 0.5, "rho": 1.0,
+                "partition": "row/column strips x%d" % world if batch == 1 else "batch sharded x%d" % world,
+                "exchange": args.exchange,
+            },
+            "label_updates_per_sec": 2.0 * V * it_per_s,
+            "iteration_bytes": b_it,
+            "iteration_gbps": b_it * it_per_s / 1e9,
+            "iteration_frac_of_hbm_peak": b_it * it_per_s / 1e9 / (HBM_PEAK_GBS * world),
+            "final_objective": {"primal": float(last[0]), "linear": float(last[1]), "dual": float(last[2])},
+            "roofline": {
+                "kernel": "chain_sweep_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "bytes_per_launch": sweep_b, "ms_per_launch": sweep_ms, "launches_timed": launches,
+                "traffic": None,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(rows, cols, k, pairwise, args.seed)
+    g.FinalizeOptimization()
+    g.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

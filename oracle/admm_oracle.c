@@ -380,15 +380,31 @@ static void chain_solve(oracle_chain *o, float *lam, int *x, long long first,
   }
 }
 
+static int g_threads = 1;
+void oracle_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+
+/* Chains are independent inside one Compute, so the baseline may run one chain
+ * per thread; results do not depend on the thread count. */
 void oracle_chain_compute_range(oracle_chain *o, int r0, int r1, int c0, int c1) {
   const int R = o->R, C = o->C, k = o->k;
   const int T = R > C ? R : C;
-  float *th = falloc((long long)T * k);
-  float *M = falloc(2LL * k);
-  unsigned char *bp = (unsigned char *)malloc((size_t)T * k + 1);
-  for (int r = r0; r < r1; r++) chain_solve(o, o->lam_row, o->xrow, (long long)r * C, 1, C, th, M, bp);
-  for (int c = c0; c < c1; c++) chain_solve(o, o->lam_col, o->xcol, c, C, R, th, M, bp);
-  free(th); free(M); free(bp);
+#ifdef _OPENMP
+#pragma omp parallel num_threads(g_threads)
+#endif
+  {
+    float *th = falloc((long long)T * k);
+    float *M = falloc(2LL * k);
+    unsigned char *bp = (unsigned char *)malloc((size_t)T * k + 1);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4) nowait
+#endif
+    for (int r = r0; r < r1; r++) chain_solve(o, o->lam_row, o->xrow, (long long)r * C, 1, C, th, M, bp);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
+#endif
+    for (int c = c0; c < c1; c++) chain_solve(o, o->lam_col, o->xcol, c, C, R, th, M, bp);
+    free(th); free(M); free(bp);
+  }
 }
 
 void oracle_chain_compute(oracle_chain *o) { oracle_chain_compute_range(o, 0, o->R, 0, o->C); }

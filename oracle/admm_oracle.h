@@ -72,6 +72,9 @@ float *oracle_edge_mu_edge(oracle_edge *o);          /* E*k*k   */
 float *oracle_edge_pot_edge(oracle_edge *o);         /* E*k*k   */
 float *oracle_edge_vertmu(oracle_edge *o);           /* V*k     */
 
+/* Threads used by oracle_chain_compute* (one chain per thread; default 1). */
+void oracle_set_threads(int n);
+
 /* ---------- chain solver (parity unpinned by the reference) ---------- */
 
 typedef struct oracle_chain oracle_chain;

@@ -48,6 +48,8 @@ def _load():
         f = getattr(lib, "oracle_edge_" + n)
         f.restype = _fp
         f.argtypes = [C.c_void_p]
+    lib.oracle_set_threads.restype = None
+    lib.oracle_set_threads.argtypes = [C.c_int]
     lib.oracle_chain_create.restype = C.c_void_p
     lib.oracle_chain_create.argtypes = [C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float, C.c_float]
     for n in ("destroy", "init", "compute", "update"):
@@ -85,6 +87,10 @@ def _i(a):
 
 
 # ---------------------------------------------------------------- inputs
+
+def set_threads(n):
+    lib.oracle_set_threads(int(n))
+
 
 def lcg_fill(seed, n):
     """n uniform [0,1) floats from the 32-bit LCG; returns (array, new_state)."""
