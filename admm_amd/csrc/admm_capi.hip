@@ -148,8 +148,11 @@ SweepShape pick_shape(int KP, long long nchains) {
 
 template <int KP, int NS, bool DUAL>
 void launch_sweep_t(const ChainArgs &a, int blocks, hipStream_t s) {
-  constexpr int U = (KP >= 64) ? 4 : 8;
-  hipLaunchKernelGGL((chain_sweep_kernel<KP, NS, U, DUAL>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+  // prefetch distance GPB groups of NS steps; 64 source labels per lane need
+  // the registers of a 2-wavefront-per-SIMD allocation
+  constexpr int GPB = (NS >= 4) ? 4 : 8;
+  constexpr int MINW = (KP >= 64) ? 2 : 4;
+  hipLaunchKernelGGL((chain_sweep_kernel<KP, NS, GPB, MINW, DUAL>), dim3(blocks), dim3(kChainBlock), 0, s, a);
 }
 
 template <bool DUAL>
@@ -330,6 +333,9 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
     return fail(nullptr, ADMM_E_ARG, "more than 2^31-1 vertices");
   if (d.solver == ADMM_SOLVER_CHAIN_MINSUM) {
     if (graph) return fail(nullptr, ADMM_E_ARG, "the chain solver needs a grid, not an edge list");
+    // the sweep addresses a chain's operands with 32-bit element offsets
+    if (((long long)d.rows + 64) * d.cols * d.k >= (1LL << 31))
+      return fail(nullptr, ADMM_E_ARG, "(rows + 64) * cols * k must stay below 2^31 per grid");
     if (d.nranks > 1 && d.batch != 1) return fail(nullptr, ADMM_E_ARG, "strips (nranks > 1) need batch == 1; shard a batch by grids instead");
     if (d.exchange != ADMM_EXCHANGE_LABELS && d.exchange != ADMM_EXCHANGE_DENSE)
       return fail(nullptr, ADMM_E_ARG, "unknown exchange mode %d", d.exchange);
@@ -351,6 +357,14 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
   c->inv_k = (float)(1.0 / (double)(float)d.k);  // Tree.cpp:25
   int rc = ADMM_OK;
   auto bail = [&](int code) { g_create_error = c->err; admm_destroy(c); return code; };
+#define HIP_TRY_BAIL(call)                                                       \
+  do {                                                                           \
+    hipError_t e__ = (call);                                                     \
+    if (e__ != hipSuccess) {                                                     \
+      c->err = std::string(#call " failed: ") + hipGetErrorString(e__);          \
+      return bail(ADMM_E_HIP);                                                   \
+    }                                                                            \
+  } while (0)
   if (hipSetDevice(d.device) != hipSuccess) { c->err = "hipSetDevice failed"; return bail(ADMM_E_HIP); }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(ADMM_E_HIP); }
 
@@ -387,8 +401,14 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
     const size_t ncol_nodes = B * (size_t)d.rows * c->st.ncols;
     const size_t Tp_r = ((size_t)d.cols + kChunk - 1) / kChunk * kChunk;
     const size_t Tp_c = ((size_t)d.rows + kChunk - 1) / kChunk * kChunk;
-    if ((rc = dev_alloc(c, &c->th_r, nrow_nodes * k)) || (rc = dev_alloc(c, &c->lam_r, nrow_nodes * k)) ||
-        (rc = dev_alloc(c, &c->m_r, nrow_nodes * k)) || (rc = dev_alloc(c, &c->lam_c, ncol_nodes * k)) ||
+    // The sweep prefetches operands up to one unrolled block (<= 64 steps)
+    // past a chain's end without predication; the slack keeps those reads
+    // inside the allocation.  A column chain's step is one strip row.
+    const size_t slack_r = 64 * (size_t)std::max(d.cols, 1) * k;
+    const size_t slack_c = 64 * (size_t)std::max(d.nranks == 1 ? d.cols : c->st.ncols, 1) * k;
+    const size_t slack = std::max(slack_r, slack_c);
+    if ((rc = dev_alloc(c, &c->th_r, nrow_nodes * k + slack)) || (rc = dev_alloc(c, &c->lam_r, nrow_nodes * k + slack)) ||
+        (rc = dev_alloc(c, &c->m_r, nrow_nodes * k + slack)) || (rc = dev_alloc(c, &c->lam_c, ncol_nodes * k + slack)) ||
         (rc = dev_alloc(c, &c->xrow_r, nrow_nodes)) || (rc = dev_alloc(c, &c->xcolT_c, ncol_nodes)) ||
         (rc = dev_alloc(c, &c->bp_r, B * c->st.nrows * Tp_r * c->KP + 16)) ||
         (rc = dev_alloc(c, &c->bp_c, B * c->st.ncols * Tp_c * c->KP + 16)) ||
@@ -396,13 +416,19 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
         (rc = dev_alloc(c, &c->d_Wt, k * k)) ||
         (rc = dev_alloc(c, &c->d_chain_min, B * ((size_t)c->st.nrows + c->st.ncols))))
       return bail(rc);
+    HIP_TRY_BAIL(hipMemset(c->th_r + nrow_nodes * k, 0, sizeof(float) * slack));
+    HIP_TRY_BAIL(hipMemset(c->lam_r + nrow_nodes * k, 0, sizeof(float) * slack));
+    HIP_TRY_BAIL(hipMemset(c->m_r + nrow_nodes * k, 0, sizeof(float) * slack));
+    HIP_TRY_BAIL(hipMemset(c->lam_c + ncol_nodes * k, 0, sizeof(float) * slack));
     if (d.nranks == 1) {
       c->th_c = c->th_r; c->m_c = c->m_r; c->xrow_c = c->xrow_r; c->xcolT_r = c->xcolT_c;
     } else {
-      if ((rc = dev_alloc(c, &c->th_c, ncol_nodes * k)) || (rc = dev_alloc(c, &c->m_c, ncol_nodes * k)) ||
+      if ((rc = dev_alloc(c, &c->th_c, ncol_nodes * k + slack)) || (rc = dev_alloc(c, &c->m_c, ncol_nodes * k + slack)) ||
           (rc = dev_alloc(c, &c->xrow_c, ncol_nodes)) || (rc = dev_alloc(c, &c->xcolT_r, nrow_nodes)) ||
           (rc = dev_alloc(c, &c->sendbuf, nrow_nodes + ncol_nodes)))
         return bail(rc);
+      HIP_TRY_BAIL(hipMemset(c->th_c + ncol_nodes * k, 0, sizeof(float) * slack));
+      HIP_TRY_BAIL(hipMemset(c->m_c + ncol_nodes * k, 0, sizeof(float) * slack));
     }
     c->n_partial = (int)std::max<size_t>(B * d.rows, 1);
     if ((rc = dev_alloc(c, &c->d_partial, (size_t)c->n_partial * 2))) return bail(rc);

@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace admm {
 
 // One set of chains that share a stride pattern (all row chains, or all
@@ -59,26 +61,46 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// KP : labels padded to a power of two (lanes b >= k idle with M = +inf)
-// NS : lanes that share one target label, each scanning KP/NS source labels
-// U  : steps whose operands are fetched together (software prefetch group)
-// DUAL: evaluate the chain minimum under theta + lambda only (no dual update,
-//       no back-pointers, no labels)
-template <int KP, int NS, int U, bool DUAL>
-__global__ __launch_bounds__(kChainBlock) void chain_sweep_kernel(const ChainArgs args) {
+// Cross-lane exchange between the NS lanes that share a target label.
+// Returns the partner's value for lane ^ d.
+template <int D>
+__device__ __forceinline__ float xor_lane_f(float v) { return __shfl_xor(v, D); }
+template <int D>
+__device__ __forceinline__ int xor_lane_i(int v) { return __shfl_xor(v, D); }
+
+// KP   : labels padded to a power of two (lanes b >= k idle with M = +inf)
+// NS   : lanes that share one target label; lane s of them scans the source
+//        labels [s*KP/NS, (s+1)*KP/NS) and holds the node operands of the
+//        steps t with t % NS == s, so one 64-lane load covers NS steps
+// GPB  : load groups (of NS steps) per unrolled block = prefetch distance
+// MINW : wavefronts per SIMD the register allocation must leave room for
+// DUAL : evaluate the chain minimum under theta + lambda only (no dual
+//        update, no back-pointers, no labels)
+//
+// Back-pointers: byte (t, b) = lowest source label attaining the minimum for
+// target b at step t.  They are packed four steps to a dword and written
+// straight from registers, dword (t/4)*KP + b of the chain's scratch; the
+// backtrack streams them back through LDS one 64-step chunk at a time.
+template <int KP, int NS, int GPB, int MINW, bool DUAL>
+__global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const ChainArgs args) {
   constexpr int LPC = KP * NS;   // lanes per chain
   constexpr int CPW = 64 / LPC;  // chains per wavefront
   constexpr int A = KP / NS;     // source labels scanned per lane
-  static_assert(LPC <= 64 && A >= 1, "bad lane layout");
-  static_assert(kChunk % (2 * U) == 0, "prefetch groups must tile a chunk");
+  constexpr int BLK = GPB * NS;  // steps per unrolled block
+  constexpr int WIN = 4 * NS;    // steps per back-pointer store (one dword per lane)
+  constexpr int DW = 16 / NS;    // back-pointer dwords per lane per chunk
+  static_assert(LPC <= 64 && A >= 1 && NS <= 8, "bad lane layout");
+  static_assert(BLK % WIN == 0 && kChunk % BLK == 0, "blocks must tile windows and chunks");
   constexpr int WPB = kChainBlock / 64;
 
-  __shared__ float s_M[WPB][CPW][KP];
-  __shared__ __attribute__((aligned(16))) uint8_t s_bp[WPB][CPW][kChunk][KP];
+  __shared__ __attribute__((aligned(16))) float s_M[WPB][CPW * KP + 64];  // messages + a dump row
   __shared__ int s_x[WPB][CPW][kChunk];
+  __shared__ __attribute__((aligned(16))) uint32_t s_bp[WPB][CPW][16 * KP];
 
   const int lane = threadIdx.x & 63;
-  const int wib = threadIdx.x >> 6;
+  // the wavefront index is the same in all 64 lanes: keep it (and what
+  // derives from it) in scalar registers
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wave = blockIdx.x * WPB + wib;
   if (wave >= args.wave_begin[args.nseg]) return;
   const int si = (args.nseg > 1 && wave >= args.wave_begin[1]) ? 1 : 0;
@@ -94,9 +116,10 @@ __global__ __launch_bounds__(kChainBlock) void chain_sweep_kernel(const ChainArg
   const int chain = cvalid ? chain_raw : sg.nchains - 1;
   const int T = sg.T;
   const bool bvalid = b < k;
-  const bool writer = cvalid && bvalid && s == 0;
+  const bool lvalid = cvalid && bvalid;
   const long long first = (long long)(chain / sg.cpg) * sg.gstride + (long long)(chain % sg.cpg) * sg.cstride;
   const float INF = __builtin_inff();
+  const float pen = args.penalty, rho = args.rho, inv_k = args.inv_k;
 
   // pairwise column of this lane's target label, kept in registers
   float Wr[A];
@@ -106,115 +129,167 @@ __global__ __launch_bounds__(kChainBlock) void chain_sweep_kernel(const ChainArg
     Wr[j] = (a < k && bvalid) ? args.Wt[a * k + b] : INF;
   }
 
-  const float *th_base = sg.theta + first * k + b;
-  const float *m_base = sg.m + first * k + b;
-  float *lam_base = sg.lam + first * k + b;
-  const long long nstride = sg.sstride * (long long)k;
+  // Addresses: a per-chain base pointer (wave-uniform when the wavefront holds
+  // one chain) plus a 32-bit element offset.  Operand loads are never
+  // predicated: steps past the chain's end and labels past k read the slack
+  // that follows every operand array, and their values are never used.
+  const unsigned nstride = (unsigned)(sg.sstride * (long long)k);
+  const float *__restrict__ th_c = sg.theta + first * k;
+  const float *__restrict__ m_c = sg.m + first * k;
+  float *lam_c = sg.lam + first * k;
+  const unsigned lane_off = (unsigned)s * nstride + (unsigned)b;  // own step of group 0
   int *xchain = sg.x + (long long)chain * T;
-  const int Tpad = (T + kChunk - 1) / kChunk * kChunk;  // whole chunks, so 16-byte flushes never cross chains
-  uint8_t *bpchain = DUAL ? nullptr : sg.bp + (long long)chain * Tpad * KP;
+  const int Tpad = (T + kChunk - 1) / kChunk * kChunk;
+  uint32_t *bpchain = DUAL ? nullptr : reinterpret_cast<uint32_t *>(sg.bp) + (long long)chain * (Tpad / 4) * KP;
 
-  float Mcur = INF;  // M_t[b] of the step just finished (same in all NS lanes)
+  float *Mrow = &s_M[wib][cs * KP];
+  // where this lane's M_new goes at sub-step u: the real slot when the lane
+  // holds that step's operands, a private dump slot otherwise
+  int m_addr[NS];
+#pragma unroll
+  for (int u = 0; u < NS; u++) m_addr[u] = (s == u) ? (cs * KP + b) : (CPW * KP + lane);
 
-  float pth[2][U], plam[2][U], pm[2][U];
-  auto fetch = [&](int buf, int tbase) {
+  float pth[GPB], plam[GPB], pm[GPB];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int t = tbase + u;
-      const bool ok = bvalid && t < T;
-      const long long off = (long long)t * nstride;
-      pth[buf][u] = ok ? th_base[off] : 0.0f;
-      plam[buf][u] = ok ? lam_base[off] : 0.0f;
-      if (!DUAL) pm[buf][u] = ok ? m_base[off] : 0.0f;
-    }
-  };
+  for (int j = 0; j < GPB; j++) {
+    const unsigned off = lane_off + (unsigned)(j * NS) * nstride;
+    pth[j] = th_c[off];
+    plam[j] = lam_c[off];
+    pm[j] = DUAL ? 0.0f : m_c[off];
+  }
+  int xnext = -1;  // previous labels of the next chunk, one 64-step chunk per chain
+  if (!DUAL) {
+    // lanes of a chain load chunk 0 into LDS now and keep chunk 1 in flight
+    for (int i = within; i < kChunk; i += LPC) s_x[wib][cs][i] = (i < T) ? xchain[i] : -1;
+  }
 
-  auto step = [&](int t, int tt, float th_in, float lam_in, float m_in) {
-    float th;
-    if (DUAL) {
-      th = th_in + lam_in;
-    } else {
-      const int xo = s_x[wib][cs][tt];
-      const float mu = chain_mu(xo, b, args.inv_k);
-      float la = lam_in;
-      la = la + args.penalty * (mu - m_in);
-      if (writer) lam_base[(long long)t * nstride] = la;
-      th = args.rho * (th_in + la) - args.penalty * (m_in - mu);
-    }
-    if (!bvalid) th = INF;
-    float Mnew;
-    int arg = 0;
-    if (t == 0) {
-      Mnew = th;
-    } else {
-      float c[A];
+  uint32_t acc = 0, keep = 0;
+
+  // One unrolled block of BLK steps starting at step tb (tt0 = tb - chunk start).
+  auto block = [&](const int tb, const int tt0, auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-      for (int j4 = 0; j4 < A; j4++) c[j4] = s_M[wib][cs][s * A + j4] + Wr[j4];
-      float best = c[0];
-#pragma unroll
-      for (int j = 1; j < A; j++) best = __builtin_fminf(best, c[j]);
-      if (!DUAL) {
-        int aj = A - 1;
-#pragma unroll
-        for (int j = A - 2; j >= 0; j--) aj = (c[j] == best) ? j : aj;
-        arg = s * A + aj;
+    for (int j = 0; j < GPB; j++) {
+      const int tg = tb + j * NS;
+      // past the chain's end only the back-pointer bookkeeping goes on, so
+      // that a partly filled window is still stored
+      const bool glive = FULL || tg < T;
+      const float th_in = pth[j], lam_in = plam[j], m_in = pm[j];
+      const size_t goff = (size_t)(unsigned)tg * nstride;  // uniform
+      {  // operands of the group one block ahead
+        const size_t poff = goff + (size_t)BLK * nstride;
+        pth[j] = (th_c + poff)[lane_off];
+        plam[j] = (lam_c + poff)[lane_off];
+        if (!DUAL) pm[j] = (m_c + poff)[lane_off];
       }
+      float th_own = INF;
+      if (DUAL) {
+        th_own = th_in + lam_in;
+      } else if (glive) {
+        const int xo = s_x[wib][cs][tt0 + j * NS + s];
+        const float mu = chain_mu(xo, b, inv_k);
+        float la = lam_in;
+        la = la + pen * (mu - m_in);                          // Tree.cpp:70
+        if (lvalid && (FULL || tg + s < T)) (lam_c + goff)[lane_off] = la;
+        th_own = rho * (th_in + la) - pen * (m_in - mu);      // Tree.cpp:85-86
+      }
+      if (!bvalid) th_own = INF;
 #pragma unroll
-      for (int d = KP; d < LPC; d <<= 1) {
-        const float ob = __shfl_xor(best, d);
-        if (!DUAL) {
-          const int oa = __shfl_xor(arg, d);
-          const bool take = (ob < best) || (ob == best && oa < arg);
-          arg = take ? oa : arg;
+      for (int u = 0; u < NS; u++) {
+        int arg = 0;
+        if (FULL || tg + u < T) {
+        float c[A];
+        if constexpr (A % 4 == 0) {
+          const float4 *mp = reinterpret_cast<const float4 *>(Mrow + s * A);
+#pragma unroll
+          for (int q = 0; q < A / 4; q++) {
+            const float4 v = mp[q];
+            c[4 * q + 0] = v.x + Wr[4 * q + 0];
+            c[4 * q + 1] = v.y + Wr[4 * q + 1];
+            c[4 * q + 2] = v.z + Wr[4 * q + 2];
+            c[4 * q + 3] = v.w + Wr[4 * q + 3];
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < A; q++) c[q] = Mrow[s * A + q] + Wr[q];
         }
-        best = __builtin_fminf(best, ob);
+        float best = c[0];
+#pragma unroll
+        for (int q = 1; q < A; q++) best = __builtin_fminf(best, c[q]);
+        if (!DUAL) {
+          int aj = A - 1;
+#pragma unroll
+          for (int q = A - 2; q >= 0; q--) aj = (c[q] == best) ? q : aj;
+          arg = s * A + aj;
+        }
+        if constexpr (NS == 2 && KP == 32) {
+          // lanes l and l^32: one swap gives both halves' values to every lane
+          const auto rb = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+          const float blo = __uint_as_float(rb[0]), bhi = __uint_as_float(rb[1]);
+          if (!DUAL) {
+            const auto ra = __builtin_amdgcn_permlane32_swap((unsigned)arg, (unsigned)arg, false, false);
+            arg = (bhi < blo) ? (int)ra[1] : (int)ra[0];  // ties keep the lower half's (lower) label
+          }
+          best = __builtin_fminf(blo, bhi);
+        } else {
+#pragma unroll
+          for (int d = KP; d < LPC; d <<= 1) {
+            const float ob = __shfl_xor(best, d);
+            if (!DUAL) {
+              const int oa = __shfl_xor(arg, d);
+              const bool take = (ob < best) || (ob == best && oa < arg);
+              arg = take ? oa : arg;
+            }
+            best = __builtin_fminf(best, ob);
+          }
+        }
+        if (j == 0 && u == 0) best = (tb == 0) ? 0.0f : best;  // M_0 = t_0
+        const float Mnew = th_own + best;
+        wave_lds_fence();
+        s_M[wib][m_addr[u]] = Mnew;
+        wave_lds_fence();
+        }
+        if (!DUAL) {
+          acc = __builtin_amdgcn_alignbit((unsigned)arg, acc, 8);
+          const int sb = j * NS + u;  // step within the block
+          if ((sb & 3) == 3) {
+            if (s == ((sb >> 2) % NS)) keep = acc;
+            if (((sb >> 2) % NS) == NS - 1) {
+              const int w0 = (tb + sb - (WIN - 1)) >> 2;  // first dword of the window
+              if (lvalid) bpchain[(long long)(w0 + s) * KP + b] = keep;
+            }
+          }
+        }
       }
-      Mnew = th + best;
     }
-    Mcur = Mnew;
-    wave_lds_fence();
-    if (s == 0) {
-      s_M[wib][cs][b] = Mnew;
-      if (!DUAL) s_bp[wib][cs][tt][b] = (uint8_t)arg;
-    }
-    wave_lds_fence();
   };
 
-  fetch(0, 0);
   for (int t0 = 0; t0 < T; t0 += kChunk) {
-    const int n = min(kChunk, T - t0);
     if (!DUAL) {
-      // previous labels of this chunk -> LDS (one coalesced load per chain)
-      wave_lds_fence();
-      for (int i = within; i < n; i += LPC) s_x[wib][cs][i] = xchain[t0 + i];
-      wave_lds_fence();
+      // labels of chunk t0 are in LDS; fetch the next chunk's while this one runs
+      if (within < kChunk && LPC >= kChunk) xnext = (t0 + kChunk + within < T) ? xchain[t0 + kChunk + within] : -1;
     }
-    for (int g = 0; g < n; g += 2 * U) {
-      // operands of the next group are requested before this group is used
-      fetch(1, t0 + g + U);
-#pragma unroll
-      for (int u = 0; u < U; u++)
-        if (g + u < n) step(t0 + g + u, g + u, pth[0][u], plam[0][u], pm[0][u]);
-      fetch(0, t0 + g + 2 * U);
-#pragma unroll
-      for (int u = 0; u < U; u++)
-        if (g + U + u < n) step(t0 + g + U + u, g + U + u, pth[1][u], plam[1][u], pm[1][u]);
+    if (t0 + kChunk <= T) {
+#pragma unroll 1
+      for (int tt = 0; tt < kChunk; tt += BLK) block(t0 + tt, tt, std::true_type{});
+    } else {
+#pragma unroll 1
+      for (int tt = 0; tt < kChunk && t0 + tt < T; tt += BLK) block(t0 + tt, tt, std::false_type{});  // tail
     }
-    if (!DUAL) {
-      // flush the chunk's back-pointers, 16 bytes per lane
+    if (!DUAL && t0 + kChunk < T) {
       wave_lds_fence();
-      const int bytes = (n * KP + 15) & ~15;
-      const uint8_t *src = &s_bp[wib][cs][0][0];
-      uint8_t *dst = bpchain + (long long)t0 * KP;
-      if (cvalid)
-        for (int o = within * 16; o < bytes; o += LPC * 16)
-          *reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(src + o);
+      if (LPC >= kChunk) {
+        s_x[wib][cs][within] = xnext;
+      } else {
+        for (int i = within; i < kChunk; i += LPC) s_x[wib][cs][i] = (t0 + kChunk + i < T) ? xchain[t0 + kChunk + i] : -1;
+      }
       wave_lds_fence();
     }
   }
 
   // lowest-index argmin of the last message, inside each chain's KP lanes
-  float bv = Mcur;
+  wave_lds_fence();
+  float bv = Mrow[b];
   int bi = b;
 #pragma unroll
   for (int d = 1; d < KP; d <<= 1) {
@@ -230,24 +305,47 @@ __global__ __launch_bounds__(kChainBlock) void chain_sweep_kernel(const ChainArg
   }
 
   // backtrack, chunk by chunk from the end; one lane per chain walks the LDS
+  // copy while the chunk before it is already being fetched into registers
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // this wavefront's own back-pointer stores
+  constexpr int VW = DW >= 4 ? 4 : DW;  // dwords per load
+  constexpr int NV = DW / VW;
+  uint32_t stage[NV][VW];
+  auto fetch_chunk = [&](int ci) {
+    const uint32_t *src = bpchain + (long long)ci * 16 * KP;
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      const int o = (v * LPC + within) * VW;
+      if constexpr (VW == 4) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(src + o);
+        stage[v][0] = q.x; stage[v][1] = q.y; stage[v][2] = q.z; stage[v][3] = q.w;
+      } else if constexpr (VW == 2) {
+        const uint2 q = *reinterpret_cast<const uint2 *>(src + o);
+        stage[v][0] = q.x; stage[v][1] = q.y;
+      } else {
+        stage[v][0] = src[o];
+      }
+    }
+  };
   int cur = bi;
-  const int nchunks = (T + kChunk - 1) / kChunk;
+  const int nchunks = Tpad / kChunk;
+  fetch_chunk(nchunks - 1);
   for (int ci = nchunks - 1; ci >= 0; ci--) {
     const int t0 = ci * kChunk;
     const int n = min(kChunk, T - t0);
-    if (ci != nchunks - 1) {  // the last chunk is still in LDS
-      wave_lds_fence();
-      const int bytes = (n * KP + 15) & ~15;
-      uint8_t *dst = &s_bp[wib][cs][0][0];
-      const uint8_t *src = bpchain + (long long)t0 * KP;
-      for (int o = within * 16; o < bytes; o += LPC * 16)
-        *reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(src + o);
-      wave_lds_fence();
+    wave_lds_fence();
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      const int o = (v * LPC + within) * VW;
+#pragma unroll
+      for (int e = 0; e < VW; e++) s_bp[wib][cs][o + e] = stage[v][e];
     }
+    wave_lds_fence();
+    if (ci > 0) fetch_chunk(ci - 1);
     if (within == 0) {
+      const uint8_t *bytes = reinterpret_cast<const uint8_t *>(&s_bp[wib][cs][0]);
       for (int tt = n - 1; tt >= 0; tt--) {
         s_x[wib][cs][tt] = cur;
-        if (t0 + tt > 0) cur = s_bp[wib][cs][tt][cur];
+        if (t0 + tt > 0) cur = bytes[(((tt >> 2) * KP + cur) << 2) + (tt & 3)];
       }
     }
     cur = __shfl(cur, cs * LPC);
