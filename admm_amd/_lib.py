@@ -63,7 +63,7 @@ def _load():
         "admm_linear_objective": (C.c_int, [vp, dp]),
         "admm_objective": (C.c_int, [vp, dp, dp]),
         "admm_objective_enqueue": (C.c_int, [vp, C.c_int]),
-        "admm_objective_read": (C.c_int, [vp, C.c_int, C.c_int, dp, dp]),
+        "admm_objective_read": (C.c_int, [vp, C.c_int, C.c_int, dp]),
         "admm_synchronize": (C.c_int, [vp]),
         "admm_finalize": (C.c_int, [vp]),
         "admm_download_labels": (C.c_int, [vp, ip]),

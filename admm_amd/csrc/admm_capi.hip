@@ -54,15 +54,19 @@ struct admm_ctx {
   float inv_k = 0.f;
   // row strip: [batch][nrows][cols][k]; column strip: [batch][rows][ncols][k].
   // With one strip the column-side pointers alias the row-side ones.
-  float *th_r = nullptr, *lam_r = nullptr, *m_r = nullptr;
-  float *th_c = nullptr, *lam_c = nullptr, *m_c = nullptr;
+  float *th_r = nullptr, *lam_r = nullptr;
+  float *th_c = nullptr, *lam_c = nullptr;
   int *xrow_r = nullptr;   // [batch][nrows][cols]   labels of my row chains
   int *xcolT_r = nullptr;  // [batch][cols][nrows]   column-chain labels on my rows
   int *xrow_c = nullptr;   // [rows][ncols]          row-chain labels on my columns
   int *xcolT_c = nullptr;  // [ncols][rows]          labels of my column chains
+  int *xo_r = nullptr;     // [batch][nrows][cols]   = xcolT_r transposed: what the row sweep reads
+  int *xo_c = nullptr;     // [batch][ncols][rows]   = xrow_c transposed: what the column sweep reads
   uint8_t *bp_r = nullptr, *bp_c = nullptr;
   float *d_W = nullptr, *d_Wsplit = nullptr, *d_Wt = nullptr;
   float *d_chain_min = nullptr;
+  double *d_chain_lin = nullptr;  // per chain: its term of the linear objective (written by Compute)
+  bool lin_valid = false;
   int *sendbuf = nullptr;
   std::vector<float> h_unary_stage;
 
@@ -184,8 +188,9 @@ launched:
 
 void fill_seg_rows(const admm_ctx *c, ChainSeg &s, bool dual) {
   const admm_desc &d = c->d;
-  s.theta = c->th_r; s.lam = c->lam_r; s.m = c->m_r; s.x = c->xrow_r; s.bp = c->bp_r;
+  s.theta = c->th_r; s.lam = c->lam_r; s.x = c->xrow_r; s.xo = c->xo_r; s.bp = c->bp_r;
   s.chain_min = dual ? c->d_chain_min : nullptr;
+  s.chain_lin = c->d_chain_lin;
   s.nchains = d.batch * c->st.nrows;
   s.T = d.cols;
   s.cpg = std::max(1, c->st.nrows);
@@ -196,8 +201,9 @@ void fill_seg_rows(const admm_ctx *c, ChainSeg &s, bool dual) {
 
 void fill_seg_cols(const admm_ctx *c, ChainSeg &s, bool dual) {
   const admm_desc &d = c->d;
-  s.theta = c->th_c; s.lam = c->lam_c; s.m = c->m_c; s.x = c->xcolT_c; s.bp = c->bp_c;
+  s.theta = c->th_c; s.lam = c->lam_c; s.x = c->xcolT_c; s.xo = c->xo_c; s.bp = c->bp_c;
   s.chain_min = dual ? c->d_chain_min + (long long)d.batch * c->st.nrows : nullptr;
+  s.chain_lin = c->d_chain_lin + (long long)d.batch * c->st.nrows;
   s.nchains = d.batch * c->st.ncols;
   s.T = d.rows;
   s.cpg = std::max(1, c->st.ncols);
@@ -216,6 +222,7 @@ int chain_sweep(admm_ctx *c, bool dual) {
   a.rho = c->d.rho;
   a.inv_k = c->inv_k;
   a.Wt = dual ? c->d_Wsplit : c->d_Wt;
+  a.Wsplit = c->d_Wsplit;
   SweepShape sh = pick_shape(c->KP, (long long)a.seg[0].nchains + a.seg[1].nchains);
   return dual ? launch_sweep<true>(c, a, sh) : launch_sweep<false>(c, a, sh);
 }
@@ -226,6 +233,15 @@ int chain_consensus(admm_ctx *c, float *m, const int *xa, const int *xbT, int nr
   const long long blocks = (long long)c->d.batch * tr * tc;
   hipLaunchKernelGGL(chain_consensus_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, m, xa,
                      xbT, nr, nc, c->d.k, c->inv_k, tc, tr * tc);
+  HIP_TRY(c, hipGetLastError());
+  return ADMM_OK;
+}
+
+int transpose_labels(admm_ctx *c, int *out, const int *in, int nr, int nc) {
+  if (nr <= 0 || nc <= 0) return ADMM_OK;
+  const int tr = (nr + 31) / 32, tc = (nc + 31) / 32;
+  const long long blocks = (long long)c->d.batch * tr * tc;
+  hipLaunchKernelGGL(transpose_labels_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, out, in, nr, nc, tc, tr * tc);
   HIP_TRY(c, hipGetLastError());
   return ADMM_OK;
 }
@@ -408,29 +424,29 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
     const size_t slack_c = 64 * (size_t)std::max(d.nranks == 1 ? d.cols : c->st.ncols, 1) * k;
     const size_t slack = std::max(slack_r, slack_c);
     if ((rc = dev_alloc(c, &c->th_r, nrow_nodes * k + slack)) || (rc = dev_alloc(c, &c->lam_r, nrow_nodes * k + slack)) ||
-        (rc = dev_alloc(c, &c->m_r, nrow_nodes * k + slack)) || (rc = dev_alloc(c, &c->lam_c, ncol_nodes * k + slack)) ||
+        (rc = dev_alloc(c, &c->lam_c, ncol_nodes * k + slack)) ||
         (rc = dev_alloc(c, &c->xrow_r, nrow_nodes)) || (rc = dev_alloc(c, &c->xcolT_c, ncol_nodes)) ||
+        (rc = dev_alloc(c, &c->xo_r, nrow_nodes)) || (rc = dev_alloc(c, &c->xo_c, ncol_nodes)) ||
         (rc = dev_alloc(c, &c->bp_r, B * c->st.nrows * Tp_r * c->KP + 16)) ||
         (rc = dev_alloc(c, &c->bp_c, B * c->st.ncols * Tp_c * c->KP + 16)) ||
         (rc = dev_alloc(c, &c->d_W, k * k)) || (rc = dev_alloc(c, &c->d_Wsplit, k * k)) ||
         (rc = dev_alloc(c, &c->d_Wt, k * k)) ||
-        (rc = dev_alloc(c, &c->d_chain_min, B * ((size_t)c->st.nrows + c->st.ncols))))
+        (rc = dev_alloc(c, &c->d_chain_min, B * ((size_t)c->st.nrows + c->st.ncols))) ||
+        (rc = dev_alloc(c, &c->d_chain_lin, B * ((size_t)c->st.nrows + c->st.ncols))))
       return bail(rc);
     HIP_TRY_BAIL(hipMemset(c->th_r + nrow_nodes * k, 0, sizeof(float) * slack));
     HIP_TRY_BAIL(hipMemset(c->lam_r + nrow_nodes * k, 0, sizeof(float) * slack));
-    HIP_TRY_BAIL(hipMemset(c->m_r + nrow_nodes * k, 0, sizeof(float) * slack));
     HIP_TRY_BAIL(hipMemset(c->lam_c + ncol_nodes * k, 0, sizeof(float) * slack));
     if (d.nranks == 1) {
-      c->th_c = c->th_r; c->m_c = c->m_r; c->xrow_c = c->xrow_r; c->xcolT_r = c->xcolT_c;
+      c->th_c = c->th_r; c->xrow_c = c->xrow_r; c->xcolT_r = c->xcolT_c;
     } else {
-      if ((rc = dev_alloc(c, &c->th_c, ncol_nodes * k + slack)) || (rc = dev_alloc(c, &c->m_c, ncol_nodes * k + slack)) ||
+      if ((rc = dev_alloc(c, &c->th_c, ncol_nodes * k + slack)) ||
           (rc = dev_alloc(c, &c->xrow_c, ncol_nodes)) || (rc = dev_alloc(c, &c->xcolT_r, nrow_nodes)) ||
           (rc = dev_alloc(c, &c->sendbuf, nrow_nodes + ncol_nodes)))
         return bail(rc);
       HIP_TRY_BAIL(hipMemset(c->th_c + ncol_nodes * k, 0, sizeof(float) * slack));
-      HIP_TRY_BAIL(hipMemset(c->m_c + ncol_nodes * k, 0, sizeof(float) * slack));
     }
-    c->n_partial = (int)std::max<size_t>(B * d.rows, 1);
+    c->n_partial = 2048;
     if ((rc = dev_alloc(c, &c->d_partial, (size_t)c->n_partial * 2))) return bail(rc);
     c->n_obj_slots = 4096;
     if ((rc = dev_alloc(c, &c->d_obj_slots, (size_t)c->n_obj_slots * 2))) return bail(rc);
@@ -557,14 +573,14 @@ int admm_init(admm_ctx *c) {
     const long long k = d.k;
     const long long nrow = (long long)d.batch * c->st.nrows * d.cols, ncol = (long long)d.batch * d.rows * c->st.ncols;
     hipLaunchKernelGGL(chain_init_theta_kernel, dim3(grid_for(nrow * k, 256)), dim3(256), 0, s, c->th_r, nrow * k, d.rho);
-    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(nrow * k, 256)), dim3(256), 0, s, c->m_r, nrow * k, c->inv_k);
     HIP_TRY(c, hipMemsetAsync(c->lam_r, 0, sizeof(float) * nrow * k, s));
     HIP_TRY(c, hipMemsetAsync(c->lam_c, 0, sizeof(float) * ncol * k, s));
     hipLaunchKernelGGL(fill_int_kernel, dim3(grid_for(nrow, 256)), dim3(256), 0, s, c->xrow_r, nrow, -1);
     hipLaunchKernelGGL(fill_int_kernel, dim3(grid_for(ncol, 256)), dim3(256), 0, s, c->xcolT_c, ncol, -1);
+    hipLaunchKernelGGL(fill_int_kernel, dim3(grid_for(nrow, 256)), dim3(256), 0, s, c->xo_r, nrow, -1);
+    hipLaunchKernelGGL(fill_int_kernel, dim3(grid_for(ncol, 256)), dim3(256), 0, s, c->xo_c, ncol, -1);
     if (d.nranks > 1) {
       hipLaunchKernelGGL(chain_init_theta_kernel, dim3(grid_for(ncol * k, 256)), dim3(256), 0, s, c->th_c, ncol * k, d.rho);
-      hipLaunchKernelGGL(fill_kernel, dim3(grid_for(ncol * k, 256)), dim3(256), 0, s, c->m_c, ncol * k, c->inv_k);
       hipLaunchKernelGGL(fill_int_kernel, dim3(grid_for(nrow, 256)), dim3(256), 0, s, c->xcolT_r, nrow, -1);
       hipLaunchKernelGGL(fill_int_kernel, dim3(grid_for(ncol, 256)), dim3(256), 0, s, c->xrow_c, ncol, -1);
     }
@@ -573,6 +589,7 @@ int admm_init(admm_ctx *c) {
   }
   HIP_TRY(c, hipStreamSynchronize(s));
   c->inited = true;
+  c->lin_valid = false;
   return ADMM_OK;
 }
 
@@ -595,6 +612,7 @@ int admm_compute(admm_ctx *c) {
   }
   rc = is_chain(c) ? chain_sweep(c, false) : edge_compute(c);
   if (rc) return rc;
+  c->lin_valid = true;
   if (c->prof) HIP_TRY(c, hipEventRecord(e1, c->stream));
   return ADMM_OK;
 }
@@ -661,8 +679,11 @@ int admm_update(admm_ctx *c) {
     HIP_TRY(c, hipGetLastError());
     return ADMM_OK;
   }
-  if ((rc = chain_consensus(c, c->m_r, c->xrow_r, c->xcolT_r, c->st.nrows, d.cols))) return rc;
-  if (d.nranks > 1 && (rc = chain_consensus(c, c->m_c, c->xrow_c, c->xcolT_c, d.rows, c->st.ncols))) return rc;
+  // The consensus of a node is a function of the two labels it received
+  // (Grid.cpp:163-181 with one-hot marginals); the sweep evaluates it from
+  // them, so Update only lays each set of labels out along the crossing chains.
+  if ((rc = transpose_labels(c, c->xo_r, c->xcolT_r, d.cols, c->st.nrows))) return rc;  // [cols][nrows] -> [nrows][cols]
+  if ((rc = transpose_labels(c, c->xo_c, c->xrow_c, d.rows, c->st.ncols))) return rc;   // [rows][ncols] -> [ncols][rows]
   return ADMM_OK;
 }
 
@@ -687,29 +708,37 @@ __global__ __launch_bounds__(256) void objective_reduce_kernel(double *__restric
 }
 }  // namespace
 
+namespace {
+// dst[1] = sum of the per-chain linear terms; dst[0] is left alone.
+__global__ __launch_bounds__(256) void linear_reduce_kernel(double *__restrict__ dst,
+                                                            const double *__restrict__ part, int n) {
+  __shared__ double s_red[4];
+  double l = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) l += part[i];
+  l = wave_sum(l);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = l;
+  __syncthreads();
+  if (threadIdx.x == 0) dst[1] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+}  // namespace
+
 // Queues the chain objective kernels; dst (device, 2 doubles) receives the
 // primal and the linear sums of this strip, not yet scaled by rho.
 static int chain_obj_enqueue(admm_ctx *c, double *dst) {
-  const admm_desc &d = c->d;
   hipStream_t s = c->stream;
   int pass = 0;
-  auto run = [&](const float *th, const int *xa, const int *xbT, int nr, int nc, int mode) -> int {
-    const int rows_total = d.batch * nr;
-    if (rows_total <= 0 || nc <= 0) return ADMM_OK;
-    if (rows_total > c->n_partial) return fail(c, ADMM_E_STATE, "objective scratch too small");
-    hipLaunchKernelGGL(chain_objective_kernel, dim3((rows_total + 3) / 4), dim3(256), 0, s, c->d_partial, th,
-                       c->d_Wsplit, xa, xbT, nr, nc, d.k, rows_total, mode);
-    hipLaunchKernelGGL(objective_reduce_kernel, dim3(1), dim3(256), 0, s, dst, c->d_partial, rows_total, pass);
+  for (int seg = 0; seg < 2; seg++) {
+    ChainSeg sg{};
+    if (seg == 0) fill_seg_rows(c, sg, false); else fill_seg_cols(c, sg, false);
+    const long long total = (long long)sg.nchains * sg.T;
+    if (total <= 0) continue;
+    const int blocks = (int)std::min<long long>(c->n_partial, (total + 255) / 256);
+    hipLaunchKernelGGL(chain_objective_kernel, dim3(blocks), dim3(256), 0, s, c->d_partial, sg.theta, c->d_Wsplit,
+                       sg.x, sg.xo, sg.nchains, sg.T, sg.cpg, sg.gstride, sg.cstride, sg.sstride, c->d.k,
+                       seg == 0 ? 1 : 0);
+    hipLaunchKernelGGL(objective_reduce_kernel, dim3(1), dim3(256), 0, s, dst, c->d_partial, blocks, pass);
     HIP_TRY(c, hipGetLastError());
     pass++;
-    return ADMM_OK;
-  };
-  int rc;
-  if (d.nranks == 1) {
-    if ((rc = run(c->th_r, c->xrow_r, c->xcolT_r, d.rows, d.cols, 3))) return rc;
-  } else {
-    if ((rc = run(c->th_r, c->xrow_r, c->xcolT_r, c->st.nrows, d.cols, 1))) return rc;
-    if ((rc = run(c->th_c, c->xrow_c, c->xcolT_c, d.rows, c->st.ncols, 2))) return rc;
   }
   if (pass == 0) HIP_TRY(c, hipMemsetAsync(dst, 0, 2 * sizeof(double), s));
   return ADMM_OK;
@@ -726,12 +755,28 @@ static int chain_obj_partials(admm_ctx *c, double *primal, double *linear) {
   return ADMM_OK;
 }
 
+static int chain_linear_enqueue(admm_ctx *c, double *dst) {
+  // After a Compute the sweep has left every chain's term in d_chain_lin.
+  const int n = c->d.batch * (c->st.nrows + c->st.ncols);
+  hipLaunchKernelGGL(linear_reduce_kernel, dim3(1), dim3(256), 0, c->stream, dst, c->d_chain_lin, n);
+  HIP_TRY(c, hipGetLastError());
+  return ADMM_OK;
+}
+
 int admm_linear_objective(admm_ctx *c, double *obj) {
   int rc = check_ctx(c);
   if (rc) return rc;
   if (!c->inited) return fail(c, ADMM_E_STATE, "objective before admm_init");
   if (!obj) return fail(c, ADMM_E_ARG, "null output");
-  if (is_chain(c)) return chain_obj_partials(c, nullptr, obj);
+  if (is_chain(c)) {
+    if (!c->lin_valid) return chain_obj_partials(c, nullptr, obj);  // before the first Compute
+    if ((rc = chain_linear_enqueue(c, c->d_obj_slots))) return rc;
+    double h[2];
+    HIP_TRY(c, hipMemcpyAsync(h, c->d_obj_slots, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *obj = h[1] * c->d.rho;
+    return ADMM_OK;
+  }
   const long long nn = (long long)c->E * 2 * c->d.k, ne = (long long)c->E * c->d.k * c->d.k;
   const int blocks = std::min(c->n_partial, grid_for(std::max(nn, ne), 256));
   hipLaunchKernelGGL(edge_objective_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_partial, c->d_pot_node,
@@ -774,10 +819,11 @@ int admm_objective_enqueue(admm_ctx *c, int slot) {
   if (!c->inited) return fail(c, ADMM_E_STATE, "objective before admm_init");
   if (!is_chain(c)) return fail(c, ADMM_E_STATE, "queued objectives are a chain-solver feature");
   if (slot < 1 || slot >= c->n_obj_slots) return fail(c, ADMM_E_ARG, "slot must be in [1, %d)", c->n_obj_slots);
-  return chain_obj_enqueue(c, c->d_obj_slots + 2 * (size_t)slot);
+  if (!c->lin_valid) return fail(c, ADMM_E_STATE, "admm_objective_enqueue needs a preceding admm_compute");
+  return chain_linear_enqueue(c, c->d_obj_slots + 2 * (size_t)slot);
 }
 
-int admm_objective_read(admm_ctx *c, int slot, int n, double *primal, double *linear) {
+int admm_objective_read(admm_ctx *c, int slot, int n, double *linear) {
   int rc = check_ctx(c);
   if (rc) return rc;
   if (!is_chain(c)) return fail(c, ADMM_E_STATE, "queued objectives are a chain-solver feature");
@@ -785,10 +831,8 @@ int admm_objective_read(admm_ctx *c, int slot, int n, double *primal, double *li
   std::vector<double> h(2 * (size_t)n);
   HIP_TRY(c, hipMemcpyAsync(h.data(), c->d_obj_slots + 2 * (size_t)slot, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  for (int i = 0; i < n; i++) {
-    if (primal) primal[i] = h[2 * i] * c->d.rho;
+  for (int i = 0; i < n; i++)
     if (linear) linear[i] = h[2 * i + 1] * c->d.rho;
-  }
   return ADMM_OK;
 }
 
@@ -853,10 +897,22 @@ int admm_download_consensus(admm_ctx *c, float *out) {
   if (rc) return rc;
   if (!c->inited) return fail(c, ADMM_E_STATE, "download before admm_init");
   if (!out) return fail(c, ADMM_E_ARG, "null output");
-  const float *src = is_chain(c) ? c->m_r : c->d_m_vert;
-  const size_t n = is_chain(c) ? (size_t)c->d.batch * c->st.nrows * c->d.cols * c->d.k : (size_t)c->V * c->d.k;
-  HIP_TRY(c, hipMemcpyAsync(out, src, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (!is_chain(c)) {
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_m_vert, sizeof(float) * (size_t)c->V * c->d.k, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ADMM_OK;
+  }
+  // the k-vectors exist only here: built from the labels on request
+  const size_t n = (size_t)c->d.batch * c->st.nrows * c->d.cols * c->d.k;
+  if (n == 0) return ADMM_OK;
+  float *tmp = nullptr;
+  HIP_TRY(c, hipMalloc((void **)&tmp, sizeof(float) * n));
+  rc = chain_consensus(c, tmp, c->xrow_r, c->xcolT_r, c->st.nrows, c->d.cols);
+  hipError_t e = rc ? hipSuccess : hipMemcpyAsync(out, tmp, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(tmp);
+  if (rc) return rc;
+  HIP_TRY(c, e);
   return ADMM_OK;
 }
 

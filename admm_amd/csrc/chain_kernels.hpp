@@ -7,6 +7,12 @@
 //   dual update      lambda += penalty * (mu - m)                  Tree.cpp:70
 //   potential adjust t = rho*(theta + lambda) - penalty*(m - mu)   Tree.cpp:85-86
 //   consensus        m = (mu_row + mu_col) / 2                     Grid.cpp:176-180
+// mu is the one-hot vector of a chain's labels, so the consensus of a node is
+// a function of the two labels it received; the sweep rebuilds it from them
+// instead of reading a k-vector per node (the k-vector is only written out
+// when a caller asks for it).  Only mu - m enters the formulas, and before
+// the first solve mu = m = 1/k (Tree.cpp:24-33), i.e. mu - m = 0: the label
+// -1 stands for that state and matches no lane.
 // The sweep itself (forward min-plus recursion with lowest-index
 // back-pointers, backtrack from the lowest argmin) has no counterpart in the
 // reference, whose only subproblem solver is the per-edge one in Tree.cpp.
@@ -27,10 +33,11 @@ namespace admm {
 struct ChainSeg {
   const float *theta;  // per-copy share of the unaries
   float *lam;          // Lagrange multipliers of these chains
-  const float *m;      // consensus
-  int *x;              // [nchains][T] labels of these chains (-1: uniform mu)
+  int *x;              // [nchains][T] labels of these chains (-1 before the first solve)
+  const int *xo;       // [nchains][T] labels the crossing chains gave the same nodes
   uint8_t *bp;         // [nchains][T][KP] back-pointer scratch
   float *chain_min;    // [nchains] (dual evaluation only)
+  double *chain_lin;   // [nchains] energy of the chain's new labels under its own share
   int nchains;
   int T;
   int cpg;
@@ -44,6 +51,7 @@ struct ChainArgs {
   int k;
   float penalty, rho, inv_k;
   const float *Wt;     // k*k, rho * (W / rho)
+  const float *Wsplit; // k*k, W / rho
 };
 
 constexpr int kChainBlock = 256;  // 4 independent wavefronts per workgroup
@@ -95,6 +103,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
 
   __shared__ __attribute__((aligned(16))) float s_M[WPB][CPW * KP + 64];  // messages + a dump row
   __shared__ int s_x[WPB][CPW][kChunk];
+  __shared__ int s_xo[WPB][CPW][kChunk];
   __shared__ __attribute__((aligned(16))) uint32_t s_bp[WPB][CPW][16 * KP];
 
   const int lane = threadIdx.x & 63;
@@ -119,7 +128,10 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   const bool lvalid = cvalid && bvalid;
   const long long first = (long long)(chain / sg.cpg) * sg.gstride + (long long)(chain % sg.cpg) * sg.cstride;
   const float INF = __builtin_inff();
-  const float pen = args.penalty, rho = args.rho, inv_k = args.inv_k;
+  const float pen = args.penalty, rho = args.rho;
+  // mu - m is (mu_own - mu_other) / 2, one of -1/2, 0, +1/2, so penalty * (mu - m)
+  // is +-hpen or 0 with hpen = penalty / 2 (exact scaling by a power of two)
+  const float hpen = pen * 0.5f;
 
   // pairwise column of this lane's target label, kept in registers
   float Wr[A];
@@ -135,10 +147,10 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // that follows every operand array, and their values are never used.
   const unsigned nstride = (unsigned)(sg.sstride * (long long)k);
   const float *__restrict__ th_c = sg.theta + first * k;
-  const float *__restrict__ m_c = sg.m + first * k;
   float *lam_c = sg.lam + first * k;
   const unsigned lane_off = (unsigned)s * nstride + (unsigned)b;  // own step of group 0
   int *xchain = sg.x + (long long)chain * T;
+  const int *xochain = DUAL ? nullptr : sg.xo + (long long)chain * T;
   const int Tpad = (T + kChunk - 1) / kChunk * kChunk;
   uint32_t *bpchain = DUAL ? nullptr : reinterpret_cast<uint32_t *>(sg.bp) + (long long)chain * (Tpad / 4) * KP;
 
@@ -149,18 +161,19 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
 #pragma unroll
   for (int u = 0; u < NS; u++) m_addr[u] = (s == u) ? (cs * KP + b) : (CPW * KP + lane);
 
-  float pth[GPB], plam[GPB], pm[GPB];
+  float pth[GPB], plam[GPB];
 #pragma unroll
   for (int j = 0; j < GPB; j++) {
     const unsigned off = lane_off + (unsigned)(j * NS) * nstride;
     pth[j] = th_c[off];
     plam[j] = lam_c[off];
-    pm[j] = DUAL ? 0.0f : m_c[off];
   }
-  int xnext = -1;  // previous labels of the next chunk, one 64-step chunk per chain
+  int xnext = -1, xonext = -1;  // labels of the next 64-step chunk, in flight
   if (!DUAL) {
-    // lanes of a chain load chunk 0 into LDS now and keep chunk 1 in flight
-    for (int i = within; i < kChunk; i += LPC) s_x[wib][cs][i] = (i < T) ? xchain[i] : -1;
+    for (int i = within; i < kChunk; i += LPC) {
+      s_x[wib][cs][i] = (i < T) ? xchain[i] : -1;
+      s_xo[wib][cs][i] = (i < T) ? xochain[i] : -1;
+    }
   }
 
   uint32_t acc = 0, keep = 0;
@@ -174,24 +187,24 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       // past the chain's end only the back-pointer bookkeeping goes on, so
       // that a partly filled window is still stored
       const bool glive = FULL || tg < T;
-      const float th_in = pth[j], lam_in = plam[j], m_in = pm[j];
+      const float th_in = pth[j], lam_in = plam[j];
       const size_t goff = (size_t)(unsigned)tg * nstride;  // uniform
       {  // operands of the group one block ahead
         const size_t poff = goff + (size_t)BLK * nstride;
         pth[j] = (th_c + poff)[lane_off];
         plam[j] = (lam_c + poff)[lane_off];
-        if (!DUAL) pm[j] = (m_c + poff)[lane_off];
       }
       float th_own = INF;
       if (DUAL) {
         th_own = th_in + lam_in;
       } else if (glive) {
-        const int xo = s_x[wib][cs][tt0 + j * NS + s];
-        const float mu = chain_mu(xo, b, inv_k);
-        float la = lam_in;
-        la = la + pen * (mu - m_in);                          // Tree.cpp:70
+        const int xown = s_x[wib][cs][tt0 + j * NS + s];
+        const int xoth = s_xo[wib][cs][tt0 + j * NS + s];
+        // p = penalty * (mu - m) = -(penalty * (m - mu)), exactly
+        const float p = ((xown == b) ? hpen : 0.0f) - ((xoth == b) ? hpen : 0.0f);
+        const float la = lam_in + p;                          // Tree.cpp:70
         if (lvalid && (FULL || tg + s < T)) (lam_c + goff)[lane_off] = la;
-        th_own = rho * (th_in + la) - pen * (m_in - mu);      // Tree.cpp:85-86
+        th_own = rho * (th_in + la) + p;                      // Tree.cpp:85-86
       }
       if (!bvalid) th_own = INF;
 #pragma unroll
@@ -200,14 +213,17 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         if (FULL || tg + u < T) {
         float c[A];
         if constexpr (A % 4 == 0) {
-          const float4 *mp = reinterpret_cast<const float4 *>(Mrow + s * A);
+          // 16-byte LDS reads, packed two-lane adds
+          typedef float f2 __attribute__((ext_vector_type(2)));
+          typedef float f4 __attribute__((ext_vector_type(4)));
+          const f4 *mp = reinterpret_cast<const f4 *>(Mrow + s * A);
 #pragma unroll
           for (int q = 0; q < A / 4; q++) {
-            const float4 v = mp[q];
-            c[4 * q + 0] = v.x + Wr[4 * q + 0];
-            c[4 * q + 1] = v.y + Wr[4 * q + 1];
-            c[4 * q + 2] = v.z + Wr[4 * q + 2];
-            c[4 * q + 3] = v.w + Wr[4 * q + 3];
+            const f4 v = mp[q];
+            const f2 lo = v.xy + f2{Wr[4 * q + 0], Wr[4 * q + 1]};
+            const f2 hi = v.zw + f2{Wr[4 * q + 2], Wr[4 * q + 3]};
+            c[4 * q + 0] = lo.x; c[4 * q + 1] = lo.y;
+            c[4 * q + 2] = hi.x; c[4 * q + 3] = hi.y;
           }
         } else {
 #pragma unroll
@@ -267,7 +283,11 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   for (int t0 = 0; t0 < T; t0 += kChunk) {
     if (!DUAL) {
       // labels of chunk t0 are in LDS; fetch the next chunk's while this one runs
-      if (within < kChunk && LPC >= kChunk) xnext = (t0 + kChunk + within < T) ? xchain[t0 + kChunk + within] : -1;
+      if (LPC >= kChunk) {
+        const bool ok = t0 + kChunk + within < T;
+        xnext = ok ? xchain[t0 + kChunk + within] : -1;
+        xonext = ok ? xochain[t0 + kChunk + within] : -1;
+      }
     }
     if (t0 + kChunk <= T) {
 #pragma unroll 1
@@ -280,8 +300,13 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       wave_lds_fence();
       if (LPC >= kChunk) {
         s_x[wib][cs][within] = xnext;
+        s_xo[wib][cs][within] = xonext;
       } else {
-        for (int i = within; i < kChunk; i += LPC) s_x[wib][cs][i] = (t0 + kChunk + i < T) ? xchain[t0 + kChunk + i] : -1;
+        for (int i = within; i < kChunk; i += LPC) {
+          const bool ok = t0 + kChunk + i < T;
+          s_x[wib][cs][i] = ok ? xchain[t0 + kChunk + i] : -1;
+          s_xo[wib][cs][i] = ok ? xochain[t0 + kChunk + i] : -1;
+        }
       }
       wave_lds_fence();
     }
@@ -328,6 +353,12 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   };
   int cur = bi;
   const int nchunks = Tpad / kChunk;
+  // The chain's term of the linear objective (Grid.cpp:1665-1680): sum of
+  // theta_share[x_t] + W[x_t][x_t+1] over the new labels, gathered chunk by
+  // chunk by all lanes while lane 0 walks the next chunk.
+  double lin = 0.0;
+  float gpend = 0.0f;  // gather of the previous chunk, still in flight
+  int carry = 0;       // label of the first node after the current chunk
   fetch_chunk(nchunks - 1);
   for (int ci = nchunks - 1; ci >= 0; ci--) {
     const int t0 = ci * kChunk;
@@ -350,10 +381,26 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     }
     cur = __shfl(cur, cs * LPC);
     wave_lds_fence();
-    if (cvalid)
-      for (int i = within; i < n; i += LPC) xchain[t0 + i] = s_x[wib][cs][i];
+    lin += (double)gpend;
+    gpend = 0.0f;
+    for (int i = within; i < n; i += LPC) {
+      const int xi = s_x[wib][cs][i];
+      if (cvalid) xchain[t0 + i] = xi;
+      const int t = t0 + i;
+      if (t + 1 < T) {
+        const int xn = (i + 1 < n) ? s_x[wib][cs][i + 1] : carry;
+        lin += (double)args.Wsplit[xi * k + xn];
+      }
+      const float g = (th_c + (size_t)(unsigned)t * nstride)[xi];
+      if (LPC >= kChunk) gpend = g; else lin += (double)g;
+    }
+    carry = s_x[wib][cs][0];
     wave_lds_fence();
   }
+  lin += (double)gpend;
+#pragma unroll
+  for (int d = 1; d < LPC; d <<= 1) lin += __shfl_xor(lin, d);
+  if (cvalid && within == 0) sg.chain_lin[chain] = lin;
 }
 
 // Consensus of a strip of nr x nc nodes from the two label arrays:
@@ -425,56 +472,70 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// Objective partials of a strip of nr x nc nodes, one wavefront per row.
-// mode bit 0 (row part, run on the strip that owns whole rows):
-//   primal += 2 * theta_share[x] + W[x][x_right]      (x = decoded label)
-//   linear += theta_share[x_row] + W[x_row][x_row_right]
-// mode bit 1 (column part, run on the strip that owns whole columns):
-//   primal += W[x][x_down]
-//   linear += theta_share[x_col] + W[x_col][x_col_down]
-// linear is the chain analogue of Grid.cpp:1665-1680 (every tree's own
-// solution under its share of the potentials).  out[2*row] = primal partial,
-// out[2*row+1] = linear partial; the host adds the partials in binary64.
+// Objective terms of one set of chains, one thread per node, on chain-major
+// label arrays (x_own: the chains' own labels, x_oth: the labels the crossing
+// chains gave the same nodes).  d = decoded label = argmax of the consensus.
+//   primal += [mode & 1] 2 * theta_share[d]  +  W[d][d_next]
+//   linear +=            theta_share[x_own]  +  W[x_own][x_own_next]
+// "next" is the next node along the chain.  The row chains are run with
+// mode 1 and the column chains with mode 0, so every unary and every edge is
+// counted once.  linear is the chain analogue of Grid.cpp:1665-1680 (every
+// tree's own solution under its share of the potentials).  Each workgroup
+// writes one (primal, linear) partial; binary64 accumulation throughout.
 __global__ __launch_bounds__(256) void chain_objective_kernel(
-    double *__restrict__ out, const float *__restrict__ theta, const float *__restrict__ Wsplit,
-    const int *__restrict__ xa, const int *__restrict__ xbT, int nr, int nc, int k,
-    int rows_total, int mode) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows_total) return;
-  const int g = row / nr, r = row % nr;
-  const long long abase = (long long)g * nr * nc + (long long)r * nc;  // xa: [g][nr][nc]
-  const long long bbase = (long long)g * nr * nc;                      // xbT: [g][nc][nr]
+    double *__restrict__ partial, const float *__restrict__ theta, const float *__restrict__ Wsplit,
+    const int *__restrict__ x_own, const int *__restrict__ x_oth, int nchains, int T, int cpg,
+    long long gstride, long long cstride, long long sstride, int k, int mode) {
+  __shared__ float s_W[64 * 64];
+  __shared__ double s_red[2][4];
+  for (int i = threadIdx.x; i < k * k; i += 256) s_W[i] = Wsplit[i];
+  __syncthreads();
+  const long long total = (long long)nchains * T;
   double p = 0.0, lin = 0.0;
-  for (int c = lane; c < nc; c += 64) {
-    const int xr = xa[abase + c], xc = xbT[bbase + (long long)c * nr + r];
-    const int x = chain_decode(xr, xc);
-    const int xr0 = xr < 0 ? 0 : xr, xc0 = xc < 0 ? 0 : xc;
-    const float *th = theta + (abase + c) * k;
+  for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int chain = (int)(idx / T), t = (int)(idx % T);
+    const int xo = x_own[idx], xt = x_oth[idx];
+    const int d = chain_decode(xo, xt);
+    const int xo0 = xo < 0 ? 0 : xo;
+    const long long node = (long long)(chain / cpg) * gstride + (long long)(chain % cpg) * cstride + (long long)t * sstride;
+    const float *th = theta + node * k;
     if (mode & 1) {
-      p += (double)th[x];
-      p += (double)th[x];
-      lin += (double)th[xr0];
-      if (c + 1 < nc) {
-        const int xr1 = xa[abase + c + 1], xc1 = xbT[bbase + (long long)(c + 1) * nr + r];
-        p += (double)Wsplit[x * k + chain_decode(xr1, xc1)];
-        lin += (double)Wsplit[xr0 * k + (xr1 < 0 ? 0 : xr1)];
-      }
+      p += (double)th[d];
+      p += (double)th[d];
     }
-    if (mode & 2) {
-      lin += (double)th[xc0];
-      if (r + 1 < nr) {
-        const int xr2 = xa[abase + nc + c], xc2 = xbT[bbase + (long long)c * nr + r + 1];
-        p += (double)Wsplit[x * k + chain_decode(xr2, xc2)];
-        lin += (double)Wsplit[xc0 * k + (xc2 < 0 ? 0 : xc2)];
-      }
+    lin += (double)th[xo0];
+    if (t + 1 < T) {
+      const int xo1 = x_own[idx + 1], xt1 = x_oth[idx + 1];
+      p += (double)s_W[d * k + chain_decode(xo1, xt1)];
+      lin += (double)s_W[xo0 * k + (xo1 < 0 ? 0 : xo1)];
     }
   }
   p = wave_sum(p);
   lin = wave_sum(lin);
-  if (lane == 0) {
-    out[2 * row] = p;
-    out[2 * row + 1] = lin;
+  if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = p; s_red[1][threadIdx.x >> 6] = lin; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    partial[2 * blockIdx.x + 1] = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+  }
+}
+
+// out[g][c][r] = in[g][r][c] for g < batch, r < nr, c < nc; 32 x 32 tiles through LDS.
+__global__ __launch_bounds__(256) void transpose_labels_kernel(int *__restrict__ out, const int *__restrict__ in,
+                                                               int nr, int nc, int tiles_c, int tiles_per_grid) {
+  __shared__ int s_t[32][33];
+  const int g = blockIdx.x / tiles_per_grid;
+  const int tile = blockIdx.x % tiles_per_grid;
+  const int r0 = (tile / tiles_c) * 32, c0 = (tile % tiles_c) * 32;
+  const long long base = (long long)g * nr * nc;
+  for (int i = threadIdx.x; i < 1024; i += 256) {
+    const int hi = i >> 5, lo = i & 31;
+    if (r0 + hi < nr && c0 + lo < nc) s_t[hi][lo] = in[base + (long long)(r0 + hi) * nc + c0 + lo];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 1024; i += 256) {
+    const int hi = i >> 5, lo = i & 31;
+    if (c0 + hi < nc && r0 + lo < nr) out[base + (long long)(c0 + hi) * nr + r0 + lo] = s_t[lo][hi];
   }
 }
 

@@ -178,11 +178,10 @@ class Grid:
         self._ck(lib.admm_objective_enqueue(self._h, int(slot)))
 
     def ObjectiveRead(self, slot, n):
-        p = np.empty(n, dtype=np.float64)
         l = np.empty(n, dtype=np.float64)
         dp = C.POINTER(C.c_double)
-        self._ck(lib.admm_objective_read(self._h, int(slot), int(n), p.ctypes.data_as(dp), l.ctypes.data_as(dp)))
-        return p, l
+        self._ck(lib.admm_objective_read(self._h, int(slot), int(n), l.ctypes.data_as(dp)))
+        return l
 
     def Synchronize(self):
         self._ck(lib.admm_synchronize(self._h))

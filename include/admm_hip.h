@@ -109,15 +109,15 @@ int admm_linear_objective(admm_ctx *ctx, double *obj);
  * Either pointer may be NULL.  Edge solver: primal = the linear objective,
  * dual = NaN.  No counterpart in the reference, which decodes no labels. */
 int admm_objective(admm_ctx *ctx, double *primal, double *dual);
-/* Chain solver: the same two sums (primal, linear) without stopping the
- * stream.  admm_objective_enqueue queues the kernels and leaves the values in
- * device slot `slot` (1 <= slot < 4096); admm_objective_read waits for the
- * stream and copies slots [slot, slot+n) out.  The reference prints its
- * objective every iteration (admm.cpp:94-99); a driver that wants the same
- * trace without a host round trip per iteration queues one slot per
+/* Chain solver: the linear objective without stopping the stream.  Compute
+ * leaves every chain's term on the device; admm_objective_enqueue queues their
+ * sum into device slot `slot` (1 <= slot < 4096) and admm_objective_read waits
+ * for the stream and copies slots [slot, slot+n) out.  The reference prints
+ * its objective every iteration (admm.cpp:94-99); a driver that wants the
+ * same trace without a host round trip per iteration queues one slot per
  * iteration and reads them at the end. */
 int admm_objective_enqueue(admm_ctx *ctx, int slot);
-int admm_objective_read(admm_ctx *ctx, int slot, int n, double *primal, double *linear);
+int admm_objective_read(admm_ctx *ctx, int slot, int n, double *linear);
 /* Waits for everything queued on the context's stream. */
 int admm_synchronize(admm_ctx *ctx);
 /* Grid::FinalizeOptimization (Grid.cpp:1414-1416): releases the communicator. */
