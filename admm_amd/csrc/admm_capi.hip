@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -147,6 +148,14 @@ SweepShape pick_shape(int KP, long long nchains) {
     if (nchains / (64 / KP) >= simd_slots) NS = 1;
   }
   if (KP == 64) NS = 1;
+  // 32 labels: two chains per wavefront (each lane scans all 32 sources, no
+  // cross-lane combine) once that still gives every SIMD two wavefronts
+  if (KP == 32 && nchains / 2 >= simd_slots) NS = 1;
+  // tuning knob: ADMM_SWEEP_NS=<n> forces the split when a kernel for it exists
+  if (const char *e = getenv("ADMM_SWEEP_NS")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= std::min(64 / KP, KP) && (v & (v - 1)) == 0 && (KP != 32 || v <= 2) && (v == 1 || v == std::min(64 / KP, KP))) NS = v;
+  }
   return {KP, NS};
 }
 
@@ -155,7 +164,9 @@ void launch_sweep_t(const ChainArgs &a, int blocks, hipStream_t s) {
   // prefetch distance GPB groups of NS steps; 64 source labels per lane need
   // the registers of a 2-wavefront-per-SIMD allocation
   constexpr int GPB = (NS >= 4) ? 4 : 8;
-  constexpr int MINW = (KP >= 64) ? 2 : 4;
+  // arg-min of 32+ candidates per lane, or a split chain (scarce chains, so
+  // occupancy is not the limit): room for 256 registers
+  constexpr int MINW = (KP / NS >= 32 || NS > 1) ? 2 : 4;
   hipLaunchKernelGGL((chain_sweep_kernel<KP, NS, GPB, MINW, DUAL>), dim3(blocks), dim3(kChainBlock), 0, s, a);
 }
 
@@ -177,7 +188,7 @@ int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
   SWEEP_CASE(4, 1) SWEEP_CASE(4, 4)
   SWEEP_CASE(8, 1) SWEEP_CASE(8, 8)
   SWEEP_CASE(16, 1) SWEEP_CASE(16, 4)
-  SWEEP_CASE(32, 2)
+  SWEEP_CASE(32, 1) SWEEP_CASE(32, 2)
   SWEEP_CASE(64, 1)
 #undef SWEEP_CASE
   return fail(c, ADMM_E_ARG, "no sweep kernel for KP=%d NS=%d", sh.KP, sh.NS);
@@ -224,6 +235,15 @@ int chain_sweep(admm_ctx *c, bool dual) {
   a.Wt = dual ? c->d_Wsplit : c->d_Wt;
   a.Wsplit = c->d_Wsplit;
   SweepShape sh = pick_shape(c->KP, (long long)a.seg[0].nchains + a.seg[1].nchains);
+  if (getenv("ADMM_SWEEP_SPLIT")) {  // diagnostic: one launch per set of chains
+    ChainArgs b = a;
+    a.nseg = 1;
+    int rc = dual ? launch_sweep<true>(c, a, sh) : launch_sweep<false>(c, a, sh);
+    if (rc) return rc;
+    b.nseg = 1;
+    b.seg[0] = b.seg[1];
+    return dual ? launch_sweep<true>(c, b, sh) : launch_sweep<false>(c, b, sh);
+  }
   return dual ? launch_sweep<true>(c, a, sh) : launch_sweep<false>(c, a, sh);
 }
 

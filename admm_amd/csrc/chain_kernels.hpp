@@ -69,6 +69,52 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Compile-time loop: f(integral_constant<int, I>) for I in [0, N).
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// Minimum of c[0..N) with three-input minima.
+template <int N>
+__device__ __forceinline__ float min_of(const float *c) {
+  float r = c[0];
+  if constexpr (N % 2 == 0) {
+    r = __builtin_fminf(r, c[1]);
+#pragma unroll
+    for (int q = 2; q + 1 < N; q += 2) r = __builtin_fminf(__builtin_fminf(r, c[q]), c[q + 1]);
+  } else {
+#pragma unroll
+    for (int q = 1; q + 1 < N; q += 2) r = __builtin_fminf(__builtin_fminf(r, c[q]), c[q + 1]);
+  }
+  return r;
+}
+
+// Lowest index i in [0, N) with c[i] == best, given that one exists.  A flat
+// scan costs a compare and a select per candidate; halving the candidate set
+// on "is the minimum in the lower half" costs one compare per level and a
+// select per surviving candidate, about two thirds of that.
+template <int N>
+__device__ __forceinline__ int first_equal(const float *c, const float best) {
+  if constexpr (N <= 4) {
+    int idx = N - 1;
+#pragma unroll
+    for (int q = N - 2; q >= 0; q--) idx = (c[q] == best) ? q : idx;
+    return idx;
+  } else {
+    constexpr int H = N / 2;
+    const bool in_lo = min_of<H>(c) == best;
+    float sel[H];
+#pragma unroll
+    for (int q = 0; q < H; q++) sel[q] = in_lo ? c[q] : c[H + q];
+    const int r = first_equal<H>(sel, best);
+    return r | (in_lo ? 0 : H);
+  }
+}
+
 // Cross-lane exchange between the NS lanes that share a target label.
 // Returns the partner's value for lane ^ d.
 template <int D>
@@ -178,28 +224,73 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
 
   uint32_t acc = 0, keep = 0;
 
+  // Software pipeline: the back-pointer of a step (which source attained the
+  // minimum) is not needed to go on, only the minimum is.  So a step's
+  // candidates are kept, and their arg-min is worked out one step later, in
+  // the shadow of that step's LDS round trip.
+  float c_prev[A];
+  float best_prev = 0.0f, blo_prev = 0.0f, bhi_prev = 0.0f;
+#pragma unroll
+  for (int q = 0; q < A; q++) c_prev[q] = 0.0f;
+
+  // Arg-min and back-pointer bookkeeping of the step at block position SBP of
+  // the block that starts at step tbp.  live = false: the step lies past the
+  // chain's end and only the packing goes on, so a partly filled window of
+  // four steps is still stored.
+  auto finish = [&](auto sbp_c, const int tbp, const bool live) {
+    constexpr int SBP = decltype(sbp_c)::value;
+    if (DUAL) return;
+    int arg = 0;
+    if (live) {
+      arg = s * A + first_equal<A>(c_prev, best_prev);
+      if constexpr (NS == 2 && KP == 32) {
+        const auto ra = __builtin_amdgcn_permlane32_swap((unsigned)arg, (unsigned)arg, false, false);
+        arg = (bhi_prev < blo_prev) ? (int)ra[1] : (int)ra[0];  // ties keep the lower half's (lower) label
+      } else if constexpr (NS > 1) {
+        // partner values were exchanged when the minimum was combined; redo
+        // the same comparisons on the (minimum, label) pairs
+        float bb = best_prev;
+#pragma unroll
+        for (int d = KP; d < LPC; d <<= 1) {
+          const float ob = __shfl_xor(bb, d);
+          const int oa = __shfl_xor(arg, d);
+          const bool take = (ob < bb) || (ob == bb && oa < arg);
+          arg = take ? oa : arg;
+          bb = __builtin_fminf(bb, ob);
+        }
+      }
+    }
+    acc = __builtin_amdgcn_alignbit((unsigned)arg, acc, 8);
+    if ((SBP & 3) == 3) {
+      if (s == ((SBP >> 2) % NS)) keep = acc;
+      if (((SBP >> 2) % NS) == NS - 1) {
+        const int w0 = (tbp + SBP - (WIN - 1)) >> 2;  // first dword of the window
+        if (lvalid) bpchain[(long long)(w0 + s) * KP + b] = keep;
+      }
+    }
+  };
+
   // One unrolled block of BLK steps starting at step tb (tt0 = tb - chunk start).
+  // The order inside a step is pinned with scheduling barriers: LDS reads
+  // first, then the previous step's arg-min (it covers the LDS latency), then
+  // the min-plus of this step.
   auto block = [&](const int tb, const int tt0, auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
-#pragma unroll
-    for (int j = 0; j < GPB; j++) {
+    int xown = -1, xoth = -1;  // labels of the current group (own step of this lane)
+    if (!DUAL) {
+      xown = s_x[wib][cs][tt0 + s];
+      xoth = s_xo[wib][cs][tt0 + s];
+    }
+    static_for<0, GPB>([&](auto j_c) {
+      constexpr int j = decltype(j_c)::value;
       const int tg = tb + j * NS;
-      // past the chain's end only the back-pointer bookkeeping goes on, so
-      // that a partly filled window is still stored
       const bool glive = FULL || tg < T;
       const float th_in = pth[j], lam_in = plam[j];
       const size_t goff = (size_t)(unsigned)tg * nstride;  // uniform
-      {  // operands of the group one block ahead
-        const size_t poff = goff + (size_t)BLK * nstride;
-        pth[j] = (th_c + poff)[lane_off];
-        plam[j] = (lam_c + poff)[lane_off];
-      }
       float th_own = INF;
       if (DUAL) {
         th_own = th_in + lam_in;
       } else if (glive) {
-        const int xown = s_x[wib][cs][tt0 + j * NS + s];
-        const int xoth = s_xo[wib][cs][tt0 + j * NS + s];
         // p = penalty * (mu - m) = -(penalty * (m - mu)), exactly
         const float p = ((xown == b) ? hpen : 0.0f) - ((xoth == b) ? hpen : 0.0f);
         const float la = lam_in + p;                          // Tree.cpp:70
@@ -207,77 +298,80 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         th_own = rho * (th_in + la) + p;                      // Tree.cpp:85-86
       }
       if (!bvalid) th_own = INF;
+      static_for<0, NS>([&](auto u_c) {
+        constexpr int u = decltype(u_c)::value;
+        const bool live = FULL || tg + u < T;
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        // (a) this step's messages leave LDS, with the next group's labels
+        //     and the operands of the group one block ahead behind them ...
+        f4 mv[(A + 3) / 4];
+        if (live) {
+          if constexpr (A % 4 == 0) {
+            const f4 *mp = reinterpret_cast<const f4 *>(Mrow + s * A);
 #pragma unroll
-      for (int u = 0; u < NS; u++) {
-        int arg = 0;
-        if (FULL || tg + u < T) {
-        float c[A];
-        if constexpr (A % 4 == 0) {
-          // 16-byte LDS reads, packed two-lane adds
-          typedef float f2 __attribute__((ext_vector_type(2)));
-          typedef float f4 __attribute__((ext_vector_type(4)));
-          const f4 *mp = reinterpret_cast<const f4 *>(Mrow + s * A);
+            for (int q = 0; q < A / 4; q++) mv[q] = mp[q];
+          } else {
 #pragma unroll
-          for (int q = 0; q < A / 4; q++) {
-            const f4 v = mp[q];
-            const f2 lo = v.xy + f2{Wr[4 * q + 0], Wr[4 * q + 1]};
-            const f2 hi = v.zw + f2{Wr[4 * q + 2], Wr[4 * q + 3]};
-            c[4 * q + 0] = lo.x; c[4 * q + 1] = lo.y;
-            c[4 * q + 2] = hi.x; c[4 * q + 3] = hi.y;
+            for (int q = 0; q < A; q++) mv[q / 4][q % 4] = Mrow[s * A + q];
           }
+        }
+        if (u == NS - 1) {
+          if (!DUAL && j + 1 < GPB) {
+            xown = s_x[wib][cs][tt0 + (j + 1) * NS + s];
+            xoth = s_xo[wib][cs][tt0 + (j + 1) * NS + s];
+          }
+          const size_t poff = goff + (size_t)BLK * nstride;
+          pth[j] = (th_c + poff)[lane_off];
+          plam[j] = (lam_c + poff)[lane_off];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // (b) ... while the previous step's back-pointer is worked out
+        if (j == 0 && u == 0) {
+          if (tb > 0) finish(std::integral_constant<int, BLK - 1>{}, tb - BLK, true);
         } else {
-#pragma unroll
-          for (int q = 0; q < A; q++) c[q] = Mrow[s * A + q] + Wr[q];
+          finish(std::integral_constant<int, (j * NS + u + BLK - 1) % BLK>{}, tb, FULL || tg + u - 1 < T);
         }
-        float best = c[0];
+        __builtin_amdgcn_sched_barrier(0);
+        // (c) min-plus of this step
+        if (live) {
+          float c[A];
+          if constexpr (A % 4 == 0) {
 #pragma unroll
-        for (int q = 1; q < A; q++) best = __builtin_fminf(best, c[q]);
-        if (!DUAL) {
-          int aj = A - 1;
-#pragma unroll
-          for (int q = A - 2; q >= 0; q--) aj = (c[q] == best) ? q : aj;
-          arg = s * A + aj;
-        }
-        if constexpr (NS == 2 && KP == 32) {
-          // lanes l and l^32: one swap gives both halves' values to every lane
-          const auto rb = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
-          const float blo = __uint_as_float(rb[0]), bhi = __uint_as_float(rb[1]);
-          if (!DUAL) {
-            const auto ra = __builtin_amdgcn_permlane32_swap((unsigned)arg, (unsigned)arg, false, false);
-            arg = (bhi < blo) ? (int)ra[1] : (int)ra[0];  // ties keep the lower half's (lower) label
-          }
-          best = __builtin_fminf(blo, bhi);
-        } else {
-#pragma unroll
-          for (int d = KP; d < LPC; d <<= 1) {
-            const float ob = __shfl_xor(best, d);
-            if (!DUAL) {
-              const int oa = __shfl_xor(arg, d);
-              const bool take = (ob < best) || (ob == best && oa < arg);
-              arg = take ? oa : arg;
+            for (int q = 0; q < A / 4; q++) {
+              const f2 lo = mv[q].xy + f2{Wr[4 * q + 0], Wr[4 * q + 1]};
+              const f2 hi = mv[q].zw + f2{Wr[4 * q + 2], Wr[4 * q + 3]};
+              c[4 * q + 0] = lo.x; c[4 * q + 1] = lo.y;
+              c[4 * q + 2] = hi.x; c[4 * q + 3] = hi.y;
             }
-            best = __builtin_fminf(best, ob);
+          } else {
+#pragma unroll
+            for (int q = 0; q < A; q++) c[q] = mv[q / 4][q % 4] + Wr[q];
           }
-        }
-        if (j == 0 && u == 0) best = (tb == 0) ? 0.0f : best;  // M_0 = t_0
-        const float Mnew = th_own + best;
-        wave_lds_fence();
-        s_M[wib][m_addr[u]] = Mnew;
-        wave_lds_fence();
-        }
-        if (!DUAL) {
-          acc = __builtin_amdgcn_alignbit((unsigned)arg, acc, 8);
-          const int sb = j * NS + u;  // step within the block
-          if ((sb & 3) == 3) {
-            if (s == ((sb >> 2) % NS)) keep = acc;
-            if (((sb >> 2) % NS) == NS - 1) {
-              const int w0 = (tb + sb - (WIN - 1)) >> 2;  // first dword of the window
-              if (lvalid) bpchain[(long long)(w0 + s) * KP + b] = keep;
-            }
+          float best;
+          if constexpr (A >= 8) best = __builtin_fminf(min_of<A / 2>(c), min_of<A / 2>(c + A / 2));
+          else best = min_of<A>(c);
+#pragma unroll
+          for (int q = 0; q < A; q++) c_prev[q] = c[q];
+          best_prev = best;
+          if constexpr (NS == 2 && KP == 32) {
+            // lanes l and l^32: one swap gives both halves' minima to every lane
+            const auto rb = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+            blo_prev = __uint_as_float(rb[0]);
+            bhi_prev = __uint_as_float(rb[1]);
+            best = __builtin_fminf(blo_prev, bhi_prev);
+          } else {
+#pragma unroll
+            for (int d = KP; d < LPC; d <<= 1) best = __builtin_fminf(best, __shfl_xor(best, d));
           }
+          if (j == 0 && u == 0) best = (tb == 0) ? 0.0f : best;  // M_0 = t_0
+          const float Mnew = th_own + best;
+          wave_lds_fence();
+          s_M[wib][m_addr[u]] = Mnew;
+          wave_lds_fence();
         }
-      }
-    }
+      });
+    });
   };
 
   for (int t0 = 0; t0 < T; t0 += kChunk) {
@@ -310,6 +404,12 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       }
       wave_lds_fence();
     }
+  }
+
+  // the last block's final position is still pending
+  if (!DUAL) {
+    const int tb_last = ((T - 1) / BLK) * BLK;
+    finish(std::integral_constant<int, BLK - 1>{}, tb_last, tb_last + BLK - 1 < T);
   }
 
   // lowest-index argmin of the last message, inside each chain's KP lanes
