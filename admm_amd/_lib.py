@@ -18,7 +18,8 @@ COMM_ID_BYTES = 128
 # every symbol include/admm_hip.h declares
 EXPORTS = [
     "admm_create", "admm_destroy", "admm_last_error", "admm_upload_unaries",
-    "admm_upload_pairwise", "admm_init", "admm_compute", "admm_communicate", "admm_update",
+    "admm_upload_pairwise", "admm_init", "admm_compute", "admm_communicate",
+    "admm_communicate_group", "admm_update",
     "admm_linear_objective", "admm_objective", "admm_objective_enqueue", "admm_objective_read", "admm_synchronize", "admm_finalize",
     "admm_download_labels", "admm_download_consensus", "admm_download_state",
     "admm_state_size", "admm_partition", "admm_strip_info", "admm_comm_get_unique_id",
@@ -59,6 +60,7 @@ def _load():
         "admm_init": (C.c_int, [vp]),
         "admm_compute": (C.c_int, [vp]),
         "admm_communicate": (C.c_int, [vp]),
+        "admm_communicate_group": (C.c_int, [C.POINTER(vp), C.c_int]),
         "admm_update": (C.c_int, [vp]),
         "admm_linear_objective": (C.c_int, [vp, dp]),
         "admm_objective": (C.c_int, [vp, dp, dp]),

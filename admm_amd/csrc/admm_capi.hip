@@ -72,6 +72,7 @@ struct admm_ctx {
   std::vector<float> h_unary_stage;
 
   ncclComm_t comm = nullptr;
+  hipEvent_t ev_packed = nullptr, ev_pulled = nullptr;  // admm_communicate_group
 
   // ---- profiling ----
   bool prof = false;
@@ -480,6 +481,8 @@ int admm_destroy(admm_ctx *c) {
   (void)hipSetDevice(c->d.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+  if (c->ev_packed) (void)hipEventDestroy(c->ev_packed);
+  if (c->ev_pulled) (void)hipEventDestroy(c->ev_pulled);
   for (auto &pr : c->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (void *p : c->allocs) (void)hipFree(p);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -637,6 +640,52 @@ int admm_compute(admm_ctx *c) {
   return ADMM_OK;
 }
 
+namespace {
+
+// Offsets (in labels) of the per-peer send blocks inside sendbuf:
+//   a-blocks: my row-chain labels on peer h's columns, nr x nc_h each, then
+//   b-blocks: my column-chain labels on peer h's rows, nc x nr_h each.
+struct ExchangePlan {
+  std::vector<long long> off_a, off_b;  // size G + 1
+  std::vector<int> r0, nr, c0, nc;      // every rank's strips
+};
+
+ExchangePlan make_plan(const admm_ctx *c) {
+  const admm_desc &d = c->d;
+  const int G = d.nranks;
+  ExchangePlan p;
+  p.off_a.assign(G + 1, 0); p.off_b.assign(G + 1, 0);
+  p.r0.resize(G); p.nr.resize(G); p.c0.resize(G); p.nc.resize(G);
+  for (int h = 0; h < G; h++) {
+    admm_partition(d.rows, G, h, &p.r0[h], &p.nr[h]);
+    admm_partition(d.cols, G, h, &p.c0[h], &p.nc[h]);
+  }
+  for (int h = 0; h < G; h++) {
+    p.off_a[h + 1] = p.off_a[h] + (long long)c->st.nrows * p.nc[h];
+    p.off_b[h + 1] = p.off_b[h] + (long long)c->st.ncols * p.nr[h];
+  }
+  return p;
+}
+
+// Gathers the strided label blocks into sendbuf (queued on the context's stream).
+int pack_labels(admm_ctx *c, const ExchangePlan &p) {
+  const admm_desc &d = c->d;
+  const int nr = c->st.nrows, nc = c->st.ncols;
+  int *send_a = c->sendbuf, *send_b = c->sendbuf + p.off_a[d.nranks];
+  for (int h = 0; h < d.nranks; h++) {
+    if (nr > 0 && p.nc[h] > 0)
+      hipLaunchKernelGGL(label_block_copy_kernel, dim3(grid_for((long long)nr * p.nc[h], 256)), dim3(256), 0, c->stream,
+                         send_a + p.off_a[h], (long long)p.nc[h], c->xrow_r + p.c0[h], (long long)d.cols, nr, p.nc[h]);
+    if (nc > 0 && p.nr[h] > 0)
+      hipLaunchKernelGGL(label_block_copy_kernel, dim3(grid_for((long long)nc * p.nr[h], 256)), dim3(256), 0, c->stream,
+                         send_b + p.off_b[h], (long long)p.nr[h], c->xcolT_c + p.r0[h], (long long)d.rows, nc, p.nr[h]);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return ADMM_OK;
+}
+
+}  // namespace
+
 int admm_communicate(admm_ctx *c) {
   int rc = check_ctx(c);
   if (rc) return rc;
@@ -647,43 +696,68 @@ int admm_communicate(admm_ctx *c) {
   hipStream_t s = c->stream;
   const int G = d.nranks;
   const int nr = c->st.nrows, nc = c->st.ncols;
-  // Pack, per peer h: my row-chain labels on h's columns (nr x nc_h) and my
-  // column-chain labels on h's rows (nc x nr_h).  Both arrive contiguous on
-  // the other side: xrow_c is [rows][nc] and xcolT_r is [cols][nr].
-  std::vector<long long> off_a(G + 1, 0), off_b(G + 1, 0);
-  for (int h = 0; h < G; h++) {
-    int c0h, nch, r0h, nrh;
-    admm_partition(d.cols, G, h, &c0h, &nch);
-    admm_partition(d.rows, G, h, &r0h, &nrh);
-    off_a[h + 1] = off_a[h] + (long long)nr * nch;
-    off_b[h + 1] = off_b[h] + (long long)nc * nrh;
-  }
-  int *send_a = c->sendbuf, *send_b = c->sendbuf + off_a[G];
-  for (int h = 0; h < G; h++) {
-    int c0h, nch, r0h, nrh;
-    admm_partition(d.cols, G, h, &c0h, &nch);
-    admm_partition(d.rows, G, h, &r0h, &nrh);
-    if (nr > 0 && nch > 0)
-      hipLaunchKernelGGL(label_block_copy_kernel, dim3(grid_for((long long)nr * nch, 256)), dim3(256), 0, s,
-                         send_a + off_a[h], (long long)nch, c->xrow_r + c0h, (long long)d.cols, nr, nch);
-    if (nc > 0 && nrh > 0)
-      hipLaunchKernelGGL(label_block_copy_kernel, dim3(grid_for((long long)nc * nrh, 256)), dim3(256), 0, s,
-                         send_b + off_b[h], (long long)nrh, c->xcolT_c + r0h, (long long)d.rows, nc, nrh);
-  }
-  HIP_TRY(c, hipGetLastError());
+  const ExchangePlan p = make_plan(c);
+  if ((rc = pack_labels(c, p))) return rc;
+  int *send_a = c->sendbuf, *send_b = c->sendbuf + p.off_a[G];
+  // Both kinds of block arrive contiguous on the other side: xrow_c is
+  // [rows][nc] (a block = whole rows of it) and xcolT_r is [cols][nr].
   NCCL_TRY(c, ncclGroupStart());
   for (int h = 0; h < G; h++) {
-    int c0h, nch, r0h, nrh;
-    admm_partition(d.cols, G, h, &c0h, &nch);
-    admm_partition(d.rows, G, h, &r0h, &nrh);
-    // a: row-chain labels.  I send (nr x nc_h); I receive h's rows on my columns (nr_h x nc).
-    if ((long long)nr * nch > 0) NCCL_TRY(c, ncclSend(send_a + off_a[h], (size_t)nr * nch, ncclInt32, h, c->comm, s));
-    if ((long long)nrh * nc > 0) NCCL_TRY(c, ncclRecv(c->xrow_c + (long long)r0h * nc, (size_t)nrh * nc, ncclInt32, h, c->comm, s));
-    // b: column-chain labels.  I send (nc x nr_h); I receive h's columns on my rows (nc_h x nr).
-    if ((long long)nc * nrh > 0) NCCL_TRY(c, ncclSend(send_b + off_b[h], (size_t)nc * nrh, ncclInt32, h, c->comm, s));
-    if ((long long)nch * nr > 0) NCCL_TRY(c, ncclRecv(c->xcolT_r + (long long)c0h * nr, (size_t)nch * nr, ncclInt32, h, c->comm, s));
+    if ((long long)nr * p.nc[h] > 0) NCCL_TRY(c, ncclSend(send_a + p.off_a[h], (size_t)nr * p.nc[h], ncclInt32, h, c->comm, s));
+    if ((long long)p.nr[h] * nc > 0) NCCL_TRY(c, ncclRecv(c->xrow_c + (long long)p.r0[h] * nc, (size_t)p.nr[h] * nc, ncclInt32, h, c->comm, s));
+    if ((long long)nc * p.nr[h] > 0) NCCL_TRY(c, ncclSend(send_b + p.off_b[h], (size_t)nc * p.nr[h], ncclInt32, h, c->comm, s));
+    if ((long long)p.nc[h] * nr > 0) NCCL_TRY(c, ncclRecv(c->xcolT_r + (long long)p.c0[h] * nr, (size_t)p.nc[h] * nr, ncclInt32, h, c->comm, s));
   }
   NCCL_TRY(c, ncclGroupEnd());
+  return ADMM_OK;
+}
+
+int admm_communicate_group(admm_ctx **ctxs, int n) {
+  if (!ctxs || n < 1) return ADMM_E_ARG;
+  for (int g = 0; g < n; g++) {
+    admm_ctx *c = ctxs[g];
+    if (!c) return ADMM_E_ARG;
+    if (!is_chain(c) || c->d.nranks != n || c->d.rank != g || c->d.rows != ctxs[0]->d.rows ||
+        c->d.cols != ctxs[0]->d.cols || c->d.k != ctxs[0]->d.k)
+      return fail(c, ADMM_E_ARG, "admm_communicate_group needs the n strips of one problem, in rank order");
+    if (!c->inited) return fail(c, ADMM_E_STATE, "admm_communicate_group before admm_init");
+  }
+  if (n == 1) return ADMM_OK;
+  std::vector<ExchangePlan> plans;
+  int rc;
+  // 1. every strip packs on its own stream and marks the point
+  for (int g = 0; g < n; g++) {
+    admm_ctx *c = ctxs[g];
+    if ((rc = check_ctx(c))) return rc;
+    plans.push_back(make_plan(c));
+    if ((rc = pack_labels(c, plans[g]))) return rc;
+    if (!c->ev_packed) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
+    if (!c->ev_pulled) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_pulled, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->ev_packed, c->stream));
+  }
+  // 2. every strip pulls its blocks on its own stream
+  for (int h = 0; h < n; h++) {
+    admm_ctx *r = ctxs[h];
+    if ((rc = check_ctx(r))) return rc;
+    const int nr = r->st.nrows, nc = r->st.ncols;
+    for (int g = 0; g < n; g++) {
+      admm_ctx *sd = ctxs[g];
+      const ExchangePlan &p = plans[g];
+      HIP_TRY(r, hipStreamWaitEvent(r->stream, sd->ev_packed, 0));
+      const int *send_a = sd->sendbuf, *send_b = sd->sendbuf + p.off_a[n];
+      const size_t na = (size_t)sd->st.nrows * nc, nb = (size_t)sd->st.ncols * nr;
+      if (na) HIP_TRY(r, hipMemcpyPeerAsync(r->xrow_c + (long long)p.r0[g] * nc, r->d.device, send_a + p.off_a[h], sd->d.device, na * sizeof(int), r->stream));
+      if (nb) HIP_TRY(r, hipMemcpyPeerAsync(r->xcolT_r + (long long)p.c0[g] * nr, r->d.device, send_b + p.off_b[h], sd->d.device, nb * sizeof(int), r->stream));
+    }
+    HIP_TRY(r, hipEventRecord(r->ev_pulled, r->stream));
+  }
+  // 3. a strip's send buffer is free again once everybody has pulled from it
+  for (int g = 0; g < n; g++) {
+    admm_ctx *c = ctxs[g];
+    if ((rc = check_ctx(c))) return rc;
+    for (int h = 0; h < n; h++)
+      if (h != g) HIP_TRY(c, hipStreamWaitEvent(c->stream, ctxs[h]->ev_pulled, 0));
+  }
   return ADMM_OK;
 }
 

@@ -213,10 +213,13 @@ class Grid:
         return out
 
     def State(self, which):
-        n = lib.admm_state_size(self._h, which)
-        if n == 0:
+        known = (0, 1, 2, 3, 4, 5) if self.part == EDGE else (10, 11, 12, 13, 14)
+        if which not in known:
             raise AdmmError(-1, "unknown state id %d" % which)
+        n = lib.admm_state_size(self._h, which)
         is_int = which in (13, 14)
+        if n == 0:  # an empty strip
+            return np.empty(0, dtype=np.int32 if is_int else np.float32)
         out = np.empty(n, dtype=np.int32 if is_int else np.float32)
         self._ck(lib.admm_download_state(self._h, which, C.cast(out.ctypes.data, _fp)))
         return out
@@ -243,6 +246,15 @@ class Grid:
     def _ck(self, rc):
         if rc != 0:
             raise AdmmError(rc, (lib.admm_last_error(self._h) or b"").decode())
+
+
+def communicate_group(grids):
+    """Label exchange between the strips of one problem held by this process
+    (Grid objects in rank order)."""
+    arr = (C.c_void_p * len(grids))(*[g._h for g in grids])
+    rc = lib.admm_communicate_group(arr, len(grids))
+    if rc != 0:
+        raise AdmmError(rc, (lib.admm_last_error(grids[0]._h) or b"").decode())
 
 
 def unique_id():

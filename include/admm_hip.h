@@ -98,6 +98,13 @@ int admm_compute(admm_ctx *ctx);
 /* Grid::Communicate (Grid.cpp:1509-1526, 1639-1663).  One strip: nothing to
  * exchange.  Several strips: RCCL all-to-all of the chain labels. */
 int admm_communicate(admm_ctx *ctx);
+/* The same exchange when all n strips of a problem live in this process (one
+ * context per strip, rank order, on one GPU or on several): device-to-device
+ * copies ordered with events between the contexts' streams, no RCCL and no
+ * host synchronisation.  The reference has no such mode (it is one process per
+ * rank); it serves single-process multi-GPU drivers and lets the strip logic be
+ * tested on one GPU. */
+int admm_communicate_group(admm_ctx **ctxs, int n);
 /* Grid::Update + UpdateMuArrAfterComm (Grid.cpp:186-193, 163-181). */
 int admm_update(admm_ctx *ctx);
 /* Grid::ComputeLinearObj (Grid.cpp:1665-1680): this strip's share of
