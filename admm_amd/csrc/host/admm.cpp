@@ -1,0 +1,113 @@
+// Driver with the reference's loop (admm.cpp:41-125): set the partitioner and
+// the penalties, describe the problem, initialise, then per iteration Compute,
+// Communicate, Update and the objective, and print the same timing labels.
+// Input is synthetic (the reference reads a PnetCDF file named by argv[1]).
+//
+//   admm <rows> <cols> <k> [--solver edge|chain] [--iters N] [--pairwise potts|trunc_linear|dense]
+//        [--seed S] [--strips G] [--batch B] [--quiet]
+//
+// --strips G cuts the grid into G row/column strips held by this one process,
+// strip g on device g modulo the device count.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+
+#include "Grid.h"
+
+static double now() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int main(int argc, char *argv[]) {
+  if (argc < 4) {
+    fprintf(stderr, "usage: %s <rows> <cols> <k> [--solver edge|chain] [--iters N] [--pairwise KIND] [--seed S] [--strips G] [--batch B] [--quiet]\n", argv[0]);
+    return 2;
+  }
+  const int rows = atoi(argv[1]), cols = atoi(argv[2]), k = atoi(argv[3]);
+  std::string solver = "edge", pairwise = "potts";
+  int totalRuns = 500, strips = 1, batch = 1;  // admm.cpp:74
+  unsigned seed = 1234;
+  bool quiet = false;
+  for (int i = 4; i < argc; i++) {
+    auto val = [&](const char *n) -> const char * {
+      if (i + 1 >= argc) { fprintf(stderr, "%s needs a value\n", n); exit(2); }
+      return argv[++i];
+    };
+    if (!strcmp(argv[i], "--solver")) solver = val("--solver");
+    else if (!strcmp(argv[i], "--iters")) totalRuns = atoi(val("--iters"));
+    else if (!strcmp(argv[i], "--pairwise")) pairwise = val("--pairwise");
+    else if (!strcmp(argv[i], "--seed")) seed = (unsigned)strtoul(val("--seed"), nullptr, 10);
+    else if (!strcmp(argv[i], "--strips")) strips = atoi(val("--strips"));
+    else if (!strcmp(argv[i], "--batch")) batch = atoi(val("--batch"));
+    else if (!strcmp(argv[i], "--quiet")) quiet = true;
+    else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
+  }
+  try {
+    const double startRun = now();
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { fprintf(stderr, "no HIP device\n"); return 1; }
+    std::vector<std::unique_ptr<Grid>> grids;
+    std::vector<Grid *> ptrs;
+    double t = now();
+    for (int g = 0; g < strips; g++) {
+      grids.emplace_back(new Grid(g, strips, g % ndev));
+      Grid &grid = *grids.back();
+      grid.SetPartitioner(solver == "edge" ? EDGE : ROW);  // admm.cpp:41
+      grid.SetPenalties(0.5, 1.0);                          // admm.cpp:44
+      grid.SetGlobalInfo(rows, cols, k, k * k);
+      grid.SetBatch(batch);
+      ptrs.push_back(&grid);
+    }
+    const double allocTime = now() - t; t = now();
+    for (auto &g : grids) g->Generate(seed, pairwise);
+    const double loadTime = now() - t; t = now();
+    for (auto &g : grids) g->InitOptimization();
+    const double initTime = now() - t; t = now();
+    double compTime = 0, commTime = 0, updateTime = 0;
+    int irun = 0;
+    while (irun++ < totalRuns) {
+      double it = now();
+      for (auto &g : grids) g->Compute();
+      compTime += now() - it; it = now();
+      if (strips > 1) Grid::CommunicateGroup(ptrs);
+      else grids[0]->Communicate();
+      commTime += now() - it; it = now();
+      for (auto &g : grids) g->Update();
+      updateTime += now() - it;
+      double totalObj = 0.0;
+      for (auto &g : grids) totalObj += g->ComputeLinearObj();  // admm.cpp:94-95
+      if (!quiet) fprintf(stderr, "totalObj:       %lf\n", totalObj);
+    }
+    if (solver != "edge") {
+      double primal = 0, dual = 0;
+      for (auto &g : grids) { double p, d; g->Objective(&p, &d); primal += p; dual += d; }
+      fprintf(stderr, "primal:          %lf\ndual:            %lf\n", primal, dual);
+    }
+    for (auto &g : grids) g->FinalizeOptimization();
+    const double optTime = now() - t;
+    const double runTime = now() - startRun;
+    // one process: max and min over ranks coincide (admm.cpp:105-110)
+    fprintf(stderr, "processes:       %d\n", strips);
+    fprintf(stderr, "allocTime:       %lf\n", allocTime);
+    fprintf(stderr, "loadTime:        %lf\n", loadTime);
+    fprintf(stderr, "initTime:        %lf\n", initTime);
+    fprintf(stderr, "optTime:         %lf\n", optTime);
+    fprintf(stderr, "maxCompTime:     %lf\n", compTime);
+    fprintf(stderr, "maxCommTime:     %lf\n", commTime);
+    fprintf(stderr, "maxUpdateTime:   %lf\n", updateTime);
+    fprintf(stderr, "minCompTime:     %lf\n", compTime);
+    fprintf(stderr, "minCommTime:     %lf\n", commTime);
+    fprintf(stderr, "minUpdateTime:   %lf\n", updateTime);
+    fprintf(stderr, "maxTotal:        %lf\n", runTime);
+  } catch (const AdmmError &e) {
+    fprintf(stderr, "admm: error %d: %s\n", e.code, e.what());
+    return 1;
+  }
+  return 0;
+}
