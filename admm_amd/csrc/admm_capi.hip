@@ -164,7 +164,7 @@ template <int KP, int NS, bool DUAL>
 void launch_sweep_t(const ChainArgs &a, int blocks, hipStream_t s) {
   // prefetch distance GPB groups of NS steps; 64 source labels per lane need
   // the registers of a 2-wavefront-per-SIMD allocation
-  constexpr int GPB = (NS >= 4) ? 4 : 8;
+  constexpr int GPB = (NS >= 4 || KP / NS >= 64) ? 4 : 8;
   // arg-min of 32+ candidates per lane, or a split chain (scarce chains, so
   // occupancy is not the limit): room for 256 registers
   constexpr int MINW = (KP / NS >= 32 || NS > 1) ? 2 : 4;

@@ -145,6 +145,9 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   constexpr int DW = 16 / NS;    // back-pointer dwords per lane per chunk
   static_assert(LPC <= 64 && A >= 1 && NS <= 8, "bad lane layout");
   static_assert(BLK % WIN == 0 && kChunk % BLK == 0, "blocks must tile windows and chunks");
+  // Work out a step's arg-min one step later (see below)?  It needs a second
+  // set of candidate registers, which 64 candidates per lane do not leave.
+  constexpr bool PIPE = A <= 32;
   constexpr int WPB = kChainBlock / 64;
 
   __shared__ __attribute__((aligned(16))) float s_M[WPB][CPW * KP + 64];  // messages + a dump row
@@ -327,12 +330,14 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         }
         __builtin_amdgcn_sched_barrier(0);
         // (b) ... while the previous step's back-pointer is worked out
-        if (j == 0 && u == 0) {
-          if (tb > 0) finish(std::integral_constant<int, BLK - 1>{}, tb - BLK, true);
-        } else {
-          finish(std::integral_constant<int, (j * NS + u + BLK - 1) % BLK>{}, tb, FULL || tg + u - 1 < T);
+        if constexpr (PIPE) {
+          if (j == 0 && u == 0) {
+            if (tb > 0) finish(std::integral_constant<int, BLK - 1>{}, tb - BLK, true);
+          } else {
+            finish(std::integral_constant<int, (j * NS + u + BLK - 1) % BLK>{}, tb, FULL || tg + u - 1 < T);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
         // (c) min-plus of this step
         if (live) {
           float c[A];
@@ -370,6 +375,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
           s_M[wib][m_addr[u]] = Mnew;
           wave_lds_fence();
         }
+        if constexpr (!PIPE) finish(std::integral_constant<int, j * NS + u>{}, tb, live);
       });
     });
   };
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   }
 
   // the last block's final position is still pending
-  if (!DUAL) {
+  if (!DUAL && PIPE) {
     const int tb_last = ((T - 1) / BLK) * BLK;
     finish(std::integral_constant<int, BLK - 1>{}, tb_last, tb_last + BLK - 1 < T);
   }
