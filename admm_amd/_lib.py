@@ -19,12 +19,13 @@ COMM_ID_BYTES = 128
 EXPORTS = [
     "admm_create", "admm_destroy", "admm_last_error", "admm_upload_unaries",
     "admm_upload_pairwise", "admm_init", "admm_compute", "admm_communicate",
-    "admm_communicate_group", "admm_update",
+    "admm_communicate_group", "admm_exchange_counts", "admm_exchange_pack_host",
+    "admm_exchange_unpack_host", "admm_update",
     "admm_linear_objective", "admm_objective", "admm_objective_enqueue", "admm_objective_read", "admm_synchronize", "admm_finalize",
     "admm_download_labels", "admm_download_consensus", "admm_download_state",
     "admm_state_size", "admm_partition", "admm_strip_info", "admm_comm_get_unique_id",
     "admm_comm_init", "admm_lcg_fill", "admm_grid_edges", "admm_profile_reset",
-    "admm_profile_read", "admm_version",
+    "admm_profile_read", "admm_device_count", "admm_version",
 ]
 
 
@@ -61,6 +62,9 @@ def _load():
         "admm_compute": (C.c_int, [vp]),
         "admm_communicate": (C.c_int, [vp]),
         "admm_communicate_group": (C.c_int, [C.POINTER(vp), C.c_int]),
+        "admm_exchange_counts": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+        "admm_exchange_pack_host": (C.c_int, [vp, ip]),
+        "admm_exchange_unpack_host": (C.c_int, [vp, ip]),
         "admm_update": (C.c_int, [vp]),
         "admm_linear_objective": (C.c_int, [vp, dp]),
         "admm_objective": (C.c_int, [vp, dp, dp]),
@@ -80,6 +84,7 @@ def _load():
         "admm_grid_edges": (C.c_int, [C.c_int, C.c_int, ip]),
         "admm_profile_reset": (C.c_int, [vp, C.c_int]),
         "admm_profile_read": (C.c_int, [vp, dp, C.POINTER(C.c_int)]),
+        "admm_device_count": (C.c_int, []),
         "admm_version": (C.c_char_p, []),
     }
     for name, (res, args) in sig.items():

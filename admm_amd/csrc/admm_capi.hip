@@ -321,6 +321,11 @@ int check_ctx(admm_ctx *c) {
 
 extern "C" {
 
+int admm_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 const char *admm_version(void) { return "admm_hip 0.1 (gfx950)"; }
 
 const char *admm_last_error(const admm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
@@ -709,6 +714,61 @@ int admm_communicate(admm_ctx *c) {
     if ((long long)p.nc[h] * nr > 0) NCCL_TRY(c, ncclRecv(c->xcolT_r + (long long)p.c0[h] * nr, (size_t)p.nc[h] * nr, ncclInt32, h, c->comm, s));
   }
   NCCL_TRY(c, ncclGroupEnd());
+  return ADMM_OK;
+}
+
+int admm_exchange_counts(admm_ctx *c, int64_t *send_counts, int64_t *recv_counts) {
+  if (!c) return ADMM_E_ARG;
+  if (!is_chain(c)) return fail(c, ADMM_E_STATE, "the label exchange belongs to the chain solver");
+  const ExchangePlan p = make_plan(c);
+  for (int h = 0; h < c->d.nranks; h++) {
+    if (send_counts) send_counts[h] = (int64_t)c->st.nrows * p.nc[h] + (int64_t)c->st.ncols * p.nr[h];
+    if (recv_counts) recv_counts[h] = (int64_t)p.nr[h] * c->st.ncols + (int64_t)p.nc[h] * c->st.nrows;
+  }
+  return ADMM_OK;
+}
+
+int admm_exchange_pack_host(admm_ctx *c, int32_t *host_send) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!is_chain(c)) return fail(c, ADMM_E_STATE, "the label exchange belongs to the chain solver");
+  if (!c->inited) return fail(c, ADMM_E_STATE, "exchange before admm_init");
+  if (!host_send) return fail(c, ADMM_E_ARG, "null buffer");
+  if (c->d.nranks == 1) return ADMM_OK;
+  const ExchangePlan p = make_plan(c);
+  if ((rc = pack_labels(c, p))) return rc;
+  const int G = c->d.nranks;
+  const int *send_a = c->sendbuf, *send_b = c->sendbuf + p.off_a[G];
+  int32_t *dst = host_send;
+  for (int h = 0; h < G; h++) {  // peer-major: [a_h | b_h]
+    const size_t na = (size_t)c->st.nrows * p.nc[h], nb = (size_t)c->st.ncols * p.nr[h];
+    if (na) HIP_TRY(c, hipMemcpyAsync(dst, send_a + p.off_a[h], na * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    dst += na;
+    if (nb) HIP_TRY(c, hipMemcpyAsync(dst, send_b + p.off_b[h], nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    dst += nb;
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ADMM_OK;
+}
+
+int admm_exchange_unpack_host(admm_ctx *c, const int32_t *host_recv) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!is_chain(c)) return fail(c, ADMM_E_STATE, "the label exchange belongs to the chain solver");
+  if (!c->inited) return fail(c, ADMM_E_STATE, "exchange before admm_init");
+  if (!host_recv) return fail(c, ADMM_E_ARG, "null buffer");
+  if (c->d.nranks == 1) return ADMM_OK;
+  const ExchangePlan p = make_plan(c);
+  const int nr = c->st.nrows, nc = c->st.ncols;
+  const int32_t *src = host_recv;
+  for (int h = 0; h < c->d.nranks; h++) {  // from peer h: its rows on my columns, then its columns on my rows
+    const size_t na = (size_t)p.nr[h] * nc, nb = (size_t)p.nc[h] * nr;
+    if (na) HIP_TRY(c, hipMemcpyAsync(c->xrow_c + (long long)p.r0[h] * nc, src, na * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    src += na;
+    if (nb) HIP_TRY(c, hipMemcpyAsync(c->xcolT_r + (long long)p.c0[h] * nr, src, nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    src += nb;
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller's buffer may be reused at once
   return ADMM_OK;
 }
 

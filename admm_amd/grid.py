@@ -161,6 +161,35 @@ class Grid:
     def Communicate(self):
         self._ck(lib.admm_communicate(self._h))
 
+    def CommunicateHost(self, dist):
+        """Communicate with the labels staged through host memory and moved by
+        torch.distributed point-to-point calls (any backend, e.g. gloo)."""
+        n = self._nprocs
+        if n == 1:
+            return
+        import torch
+        sc = (C.c_int64 * n)()
+        rcnt = (C.c_int64 * n)()
+        self._ck(lib.admm_exchange_counts(self._h, sc, rcnt))
+        send = np.empty(max(1, sum(sc)), dtype=np.int32)
+        recv = np.empty(max(1, sum(rcnt)), dtype=np.int32)
+        self._ck(lib.admm_exchange_pack_host(self._h, send.ctypes.data_as(_ip)))
+        ts, tr = torch.from_numpy(send), torch.from_numpy(recv)
+        so = np.concatenate([[0], np.cumsum(list(sc))]).astype(np.int64)
+        ro = np.concatenate([[0], np.cumsum(list(rcnt))]).astype(np.int64)
+        reqs = []
+        for h in range(n):
+            if h == self._rank:
+                tr[ro[h]:ro[h + 1]] = ts[so[h]:so[h + 1]]
+                continue
+            if sc[h]:
+                reqs.append(dist.isend(ts[so[h]:so[h + 1]], h))
+            if rcnt[h]:
+                reqs.append(dist.irecv(tr[ro[h]:ro[h + 1]], h))
+        for q in reqs:
+            q.wait()
+        self._ck(lib.admm_exchange_unpack_host(self._h, recv.ctypes.data_as(_ip)))
+
     def Update(self):
         self._ck(lib.admm_update(self._h))
 

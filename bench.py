@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default="labels", choices=["labels", "dense"])
+    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "host"],
+                    help="N > 1: RCCL send/recv inside admm_communicate, or labels staged through the host "
+                         "and moved by gloo; auto tries RCCL and falls back to host if its bootstrap fails")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -112,7 +115,10 @@ def main():
     else:
         b0 = 0
 
-    g = A.Grid(rank=rank if nprocs_for_grid > 1 else 0, nprocs=nprocs_for_grid, device=local_rank)
+    ndev = A._lib.lib.admm_device_count()
+    if ndev < 1:
+        sys.exit("bench.py needs a HIP device (there is no CPU fallback)")
+    g = A.Grid(rank=rank if nprocs_for_grid > 1 else 0, nprocs=nprocs_for_grid, device=local_rank % ndev)
     g.SetPartitioner(A.ROW)
     g.SetPenalties(0.5, 1.0)  # admm.cpp:44
     g.SetGlobalInfo(rows, cols, k, batch=my_batch)
@@ -120,10 +126,27 @@ def main():
     g.Generate(seed=args.seed + b0, pairwise=pairwise)
     g.InitOptimization()
     g._unary = None  # the host copy is no longer needed
+    transport = "none"
     if nprocs_for_grid > 1:
-        ids = [A.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        g.CommInit(ids[0])
+        transport = args.transport
+        if transport in ("auto", "rccl"):
+            import torch
+            ok = 1
+            try:
+                ids = [A.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                g.CommInit(ids[0])
+            except A.AdmmError as e:
+                ok = 0
+                sys.stderr.write("rank %d: RCCL bootstrap failed: %s\n" % (rank, e))
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag[0]) == 1:
+                transport = "rccl"
+            elif transport == "rccl":
+                sys.exit("RCCL bootstrap failed and --transport rccl was requested")
+            else:
+                transport = "host"
 
     def barrier():
         g.Synchronize()
@@ -133,7 +156,10 @@ def main():
 
     def step(i):
         g.Compute()
-        g.Communicate()
+        if transport == "host":
+            g.CommunicateHost(dist)
+        else:
+            g.Communicate()
         g.Update()
         g.ObjectiveEnqueue(1 + i)
 
@@ -191,7 +217,7 @@ def main():
                 "workload": args.workload, "rows": rows, "cols": cols, "k": k, "batch": batch,
                 "pairwise": pairwise, "solver": "chain_minsum", "penalty": 0.5, "rho": 1.0,
                 "partition": "row/column strips x%d" % world if batch == 1 else "batch sharded x%d" % world,
-                "exchange": args.exchange,
+                "exchange": args.exchange, "transport": transport,
             },
             "label_updates_per_sec": 2.0 * V * it_per_s,
             "iteration_bytes": b_it,

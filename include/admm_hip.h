@@ -105,6 +105,15 @@ int admm_communicate(admm_ctx *ctx);
  * rank); it serves single-process multi-GPU drivers and lets the strip logic be
  * tested on one GPU. */
 int admm_communicate_group(admm_ctx **ctxs, int n);
+/* The same exchange staged through host memory, for a caller that brings its
+ * own transport (the reference's is MPI_Isend / MPI_Irecv on packed host
+ * buffers, Grid.cpp:1648-1662).  admm_exchange_counts gives the labels sent to
+ * and received from every rank; admm_exchange_pack_host fills host_send,
+ * peer-major, and waits for it; the caller moves block h of every rank to
+ * rank h; admm_exchange_unpack_host takes the received blocks, peer-major. */
+int admm_exchange_counts(admm_ctx *ctx, int64_t *send_counts, int64_t *recv_counts);
+int admm_exchange_pack_host(admm_ctx *ctx, int32_t *host_send);
+int admm_exchange_unpack_host(admm_ctx *ctx, const int32_t *host_recv);
 /* Grid::Update + UpdateMuArrAfterComm (Grid.cpp:186-193, 163-181). */
 int admm_update(admm_ctx *ctx);
 /* Grid::ComputeLinearObj (Grid.cpp:1665-1680): this strip's share of
@@ -173,6 +182,9 @@ int admm_grid_edges(int rows, int cols, int32_t *edge_list);
  * the context's stream, and how many launches that covers. */
 int admm_profile_reset(admm_ctx *ctx, int enable);
 int admm_profile_read(admm_ctx *ctx, double *compute_ms_avg, int *launches);
+
+/* Number of HIP devices visible to this process (0 when there is none). */
+int admm_device_count(void);
 
 /* Library version string. */
 const char *admm_version(void);

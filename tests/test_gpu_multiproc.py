@@ -1,0 +1,76 @@
+"""Two processes, one strip each, sharing the GPU: the strip path through the C ABI with
+the label exchange staged through the host and moved by gloo.  (RCCL refuses two ranks on
+one device, so on a one-GPU box this is the transport that can be exercised; the RCCL
+transport runs the same pack / unpack plan.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, R, C, k, iters, pw, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import admm_amd as A  # the HIP library before torch: one HIP runtime in the process
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    un, W = O.synth_problem(R, C, k, 1234, pw)
+    g = A.Grid(rank=rank, nprocs=world, device=0)
+    g.SetPartitioner(A.ROW)
+    g.SetPenalties(0.5, 1.0)
+    g.SetGlobalInfo(R, C, k)
+    g.Load(un, W)
+    g.InitOptimization()
+    lin = []
+    for _ in range(iters):
+        g.Compute()
+        g.CommunicateHost(dist)
+        g.Update()
+        lin.append(g.ComputeLinearObj())
+    p, d = g.Objective()
+    r0, nr, c0, nc = g.StripInfo()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), labels=g.Labels().reshape(nr, C), lam=g.State(10),
+             lin=np.array(lin), pd=np.array([p, d]), r0=r0)
+    g.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,R,C,k,pw", [(2, 40, 70, 32, "potts"), (3, 33, 20, 8, "dense")])
+def test_two_processes_one_strip_each(tmp_path, world, R, C, k, pw):
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    iters = 6
+    mp.get_context("spawn")
+    mp.spawn(_worker, args=(world, _free_port(), R, C, k, iters, pw, str(tmp_path)), nprocs=world, join=True)
+    un, W = O.synth_problem(R, C, k, 1234, pw)
+    o = O.ChainOracle(R, C, k, un, W)
+    o.init()
+    lin_ref = []
+    for _ in range(iters):
+        o.compute(); o.update()
+        lin_ref.append(o.objective()[2])
+    po, do, _ = o.objective()
+    lin = np.zeros(iters)
+    pd = np.zeros(2)
+    for rank in range(world):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        r0, nr = int(z["r0"]), z["labels"].shape[0]
+        assert np.array_equal(z["labels"], o.labels()[r0:r0 + nr])
+        assert np.array_equal(z["lam"].reshape(nr, C, k), o.lambda_row[r0:r0 + nr])
+        lin += z["lin"]
+        pd += z["pd"]
+    np.testing.assert_allclose(lin, np.array(lin_ref), rtol=1e-9)
+    np.testing.assert_allclose(pd, np.array([po, do]), rtol=1e-9)
