@@ -236,6 +236,33 @@ int chain_sweep(admm_ctx *c, bool dual) {
   a.Wt = dual ? c->d_Wsplit : c->d_Wt;
   a.Wsplit = c->d_Wsplit;
   SweepShape sh = pick_shape(c->KP, (long long)a.seg[0].nchains + a.seg[1].nchains);
+  if (!dual && getenv("ADMM_SWEEP_STAMPS")) {
+    // diagnostic: per-wavefront clock stamps (start, end of forward pass, end), summarised on stderr
+    const size_t nw = (size_t)a.seg[0].nchains + a.seg[1].nchains + 8;
+    unsigned long long *d_st = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&d_st, nw * 3 * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMemset(d_st, 0, nw * 3 * sizeof(unsigned long long)));
+    a.stamps = d_st;
+    int rc = launch_sweep<false>(c, a, sh);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<unsigned long long> h(nw * 3);
+    HIP_TRY(c, hipMemcpy(h.data(), d_st, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    (void)hipFree(d_st);
+    std::vector<double> fw, bt;
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (size_t w = 0; w < nw; w++) {
+      if (!h[3 * w + 2]) continue;
+      fw.push_back((double)(h[3 * w + 1] - h[3 * w]));
+      bt.push_back((double)(h[3 * w + 2] - h[3 * w + 1]));
+      t0 = std::min(t0, h[3 * w]); t1 = std::max(t1, h[3 * w + 2]);
+    }
+    std::sort(fw.begin(), fw.end()); std::sort(bt.begin(), bt.end());
+    if (!fw.empty())
+      fprintf(stderr, "sweep stamps: %zu waves, forward median %.0f max %.0f, backtrack median %.0f max %.0f, span %.0f (clock ticks)\n",
+              fw.size(), fw[fw.size() / 2], fw.back(), bt[bt.size() / 2], bt.back(), (double)(t1 - t0));
+    return ADMM_OK;
+  }
   if (getenv("ADMM_SWEEP_SPLIT")) {  // diagnostic: one launch per set of chains
     ChainArgs b = a;
     a.nseg = 1;

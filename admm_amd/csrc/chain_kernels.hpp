@@ -52,6 +52,7 @@ struct ChainArgs {
   float penalty, rho, inv_k;
   const float *Wt;     // k*k, rho * (W / rho)
   const float *Wsplit; // k*k, W / rho
+  unsigned long long *stamps;  // diagnostics: 3 clock reads per wavefront, or null
 };
 
 constexpr int kChainBlock = 256;  // 4 independent wavefronts per workgroup
@@ -147,10 +148,21 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   static_assert(BLK % WIN == 0 && kChunk % BLK == 0, "blocks must tile windows and chunks");
   // Work out a step's arg-min one step later (see below)?  It needs a second
   // set of candidate registers, which 64 candidates per lane do not leave.
-  constexpr bool PIPE = A <= 32;
+  // Many candidates per lane: keep only the minima of groups of four and, once
+  // the group that holds the first minimum is known, form its four candidates
+  // again from LDS (messages of the step, pairwise column of the lane).  That
+  // replaces a select per candidate per halving level with two LDS reads.  The
+  // messages of a step must then outlive the step: two alternating rows.
+  constexpr bool RECOMP = !DUAL && NS == 1 && A >= 32;
+  constexpr int NG = A / 4;      // candidate groups per lane
+  constexpr int NB = RECOMP ? 2 : 1;
+  constexpr int WLD = KP + 4;    // padded row of the LDS pairwise table
+  constexpr bool PIPE = RECOMP || A <= 32;
   constexpr int WPB = kChainBlock / 64;
+  constexpr int MROW = CPW * KP + 64;
 
-  __shared__ __attribute__((aligned(16))) float s_M[WPB][CPW * KP + 64];  // messages + a dump row
+  __shared__ __attribute__((aligned(16))) float s_M[WPB][NB * MROW];  // messages + a dump row
+  __shared__ __attribute__((aligned(16))) float s_W[RECOMP ? KP * WLD : 4];  // [target][source]
   __shared__ int s_x[WPB][CPW][kChunk];
   __shared__ int s_xo[WPB][CPW][kChunk];
   __shared__ __attribute__((aligned(16))) uint32_t s_bp[WPB][CPW][16 * KP];
@@ -164,6 +176,8 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   const int si = (args.nseg > 1 && wave >= args.wave_begin[1]) ? 1 : 0;
   const ChainSeg &sg = args.seg[si];
 
+  unsigned long long st0 = 0;
+  if (args.stamps) st0 = __builtin_readcyclecounter();
   const int cs = lane / LPC;
   const int within = lane % LPC;
   const int s = within / KP;
@@ -188,6 +202,16 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   for (int j = 0; j < A; j++) {
     const int a = s * A + j;
     Wr[j] = (a < k && bvalid) ? args.Wt[a * k + b] : INF;
+  }
+
+  if constexpr (RECOMP) {
+    // every wavefront of the block writes the whole table (same values), so
+    // no block-wide barrier is needed before its own reads
+    for (int i = lane; i < KP * KP; i += 64) {
+      const int bb = i / KP, a = i % KP;
+      s_W[bb * WLD + a] = (a < k && bb < k) ? args.Wt[a * k + bb] : INF;
+    }
+    wave_lds_fence();
   }
 
   // Addresses: a per-chain base pointer (wave-uniform when the wavefront holds
@@ -231,10 +255,11 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // minimum) is not needed to go on, only the minimum is.  So a step's
   // candidates are kept, and their arg-min is worked out one step later, in
   // the shadow of that step's LDS round trip.
-  float c_prev[A];
+  constexpr int NPREV = RECOMP ? NG : A;
+  float c_prev[NPREV];  // candidates of the step, or the minima of their groups
   float best_prev = 0.0f, blo_prev = 0.0f, bhi_prev = 0.0f;
 #pragma unroll
-  for (int q = 0; q < A; q++) c_prev[q] = 0.0f;
+  for (int q = 0; q < NPREV; q++) c_prev[q] = 0.0f;
 
   // Arg-min and back-pointer bookkeeping of the step at block position SBP of
   // the block that starts at step tbp.  live = false: the step lies past the
@@ -245,7 +270,18 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     if (DUAL) return;
     int arg = 0;
     if (live) {
-      arg = s * A + first_equal<A>(c_prev, best_prev);
+      if constexpr (RECOMP) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const int grp = first_equal<NG>(c_prev, best_prev);
+        // the step's messages are still in the row it read them from
+        const f4 m4 = *reinterpret_cast<const f4 *>(&s_M[wib][(SBP & 1) * MROW + cs * KP + 4 * grp]);
+        const f4 w4 = *reinterpret_cast<const f4 *>(&s_W[b * WLD + 4 * grp]);
+        const f4 c4 = m4 + w4;
+        const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
+        arg = 4 * grp + first_equal<4>(cc, best_prev);
+      } else {
+        arg = s * A + first_equal<A>(c_prev, best_prev);
+      }
       if constexpr (NS == 2 && KP == 32) {
         const auto ra = __builtin_amdgcn_permlane32_swap((unsigned)arg, (unsigned)arg, false, false);
         arg = (bhi_prev < blo_prev) ? (int)ra[1] : (int)ra[0];  // ties keep the lower half's (lower) label
@@ -263,6 +299,10 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         }
       }
     }
+    // With one or two chains per wavefront the byte stored is the LANE that
+    // holds the source label (label + chain slot * lanes per chain): the
+    // backtrack then uses it as a v_readlane selector as it stands.
+    if constexpr (CPW <= 2) arg += cs * LPC;
     acc = __builtin_amdgcn_alignbit((unsigned)arg, acc, 8);
     if ((SBP & 3) == 3) {
       if (s == ((SBP >> 2) % NS)) keep = acc;
@@ -311,7 +351,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         f4 mv[(A + 3) / 4];
         if (live) {
           if constexpr (A % 4 == 0) {
-            const f4 *mp = reinterpret_cast<const f4 *>(Mrow + s * A);
+            const f4 *mp = reinterpret_cast<const f4 *>(Mrow + (RECOMP ? ((j * NS + u) & 1) * MROW : 0) + s * A);
 #pragma unroll
             for (int q = 0; q < A / 4; q++) mv[q] = mp[q];
           } else {
@@ -354,10 +394,16 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
             for (int q = 0; q < A; q++) c[q] = mv[q / 4][q % 4] + Wr[q];
           }
           float best;
-          if constexpr (A >= 8) best = __builtin_fminf(min_of<A / 2>(c), min_of<A / 2>(c + A / 2));
-          else best = min_of<A>(c);
+          if constexpr (RECOMP) {
 #pragma unroll
-          for (int q = 0; q < A; q++) c_prev[q] = c[q];
+            for (int q = 0; q < NG; q++) c_prev[q] = min_of<4>(c + 4 * q);
+            best = __builtin_fminf(min_of<NG / 2>(c_prev), min_of<NG / 2>(c_prev + NG / 2));
+          } else {
+            if constexpr (A >= 8) best = __builtin_fminf(min_of<A / 2>(c), min_of<A / 2>(c + A / 2));
+            else best = min_of<A>(c);
+#pragma unroll
+            for (int q = 0; q < A; q++) c_prev[q] = c[q];
+          }
           best_prev = best;
           if constexpr (NS == 2 && KP == 32) {
             // lanes l and l^32: one swap gives both halves' minima to every lane
@@ -372,7 +418,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
           if (j == 0 && u == 0) best = (tb == 0) ? 0.0f : best;  // M_0 = t_0
           const float Mnew = th_own + best;
           wave_lds_fence();
-          s_M[wib][m_addr[u]] = Mnew;
+          s_M[wib][(RECOMP ? (((j * NS + u) & 1) ^ 1) * MROW : 0) + m_addr[u]] = Mnew;
           wave_lds_fence();
         }
         if constexpr (!PIPE) finish(std::integral_constant<int, j * NS + u>{}, tb, live);
@@ -420,7 +466,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
 
   // lowest-index argmin of the last message, inside each chain's KP lanes
   wave_lds_fence();
-  float bv = Mrow[b];
+  float bv = Mrow[(RECOMP ? (T & 1) * MROW : 0) + b];  // step T-1 wrote row T & 1
   int bi = b;
 #pragma unroll
   for (int d = 1; d < KP; d <<= 1) {
@@ -435,9 +481,164 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     return;
   }
 
+  if (args.stamps && lane == 0) {
+    args.stamps[3 * (size_t)wave] = st0;
+    args.stamps[3 * (size_t)wave + 1] = __builtin_readcyclecounter();
+  }
   // backtrack, chunk by chunk from the end; one lane per chain walks the LDS
   // copy while the chunk before it is already being fetched into registers
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // this wavefront's own back-pointer stores
+  const int nchunks = Tpad / kChunk;
+  if constexpr (CPW <= 2) {
+    // One or two chains per wavefront: the walk runs on the scalar unit.  Lane
+    // b keeps its label's sixteen back-pointer dwords of the chunk in
+    // registers; a step is one v_readlane (lane = current label) and one bit
+    // field extract, with no LDS round trip.  The labels are collected in one
+    // register per chain (lane tt = step tt of the chunk).
+    uint32_t bpr[16], bpn[16];
+    auto load_chunk = [&](uint32_t (&dst)[16], int ci) {
+      const uint32_t *src = bpchain + (long long)ci * 16 * KP + b;
+#pragma unroll
+      for (int i = 0; i < 16; i++) dst[i] = src[i * KP];
+    };
+    int curs[CPW], carry[CPW], wtmp[2] = {0, 0};
+    double linc[CPW];
+    float gp[CPW], wp[CPW];
+    const float *thb[CPW];  // uniform base pointers of the chains of this wavefront
+    int *xcb[CPW];
+    bool cval[CPW];
+#pragma unroll
+    for (int q = 0; q < CPW; q++) {
+      curs[q] = q * LPC + __builtin_amdgcn_readlane(bi, q * LPC);  // lane holding the chain's last label
+      carry[q] = 0;
+      linc[q] = 0.0;
+      gp[q] = wp[q] = 0.0f;
+      const int craw = (wave - args.wave_begin[si]) * CPW + q;
+      cval[q] = craw < sg.nchains;
+      const int cq = cval[q] ? craw : sg.nchains - 1;
+      const long long fq = (long long)(cq / sg.cpg) * sg.gstride + (long long)(cq % sg.cpg) * sg.cstride;
+      thb[q] = sg.theta + fq * k;
+      xcb[q] = sg.x + (long long)cq * T;
+    }
+    // back-pointers are fetched two chunks ahead of the walk (bpr: this chunk,
+    // bpn: the next one, bpf: in flight); scheduling barriers keep the loads
+    // where they are written
+    uint32_t bpf[16];
+    load_chunk(bpr, nchunks - 1);
+    if (nchunks > 1) load_chunk(bpn, nchunks - 2);
+    for (int ci = nchunks - 1; ci >= 0; ci--) {
+      const int t0 = ci * kChunk;
+      const int n = min(kChunk, T - t0);
+      if (ci > 1) load_chunk(bpf, ci - 2);
+      __builtin_amdgcn_sched_barrier(0);
+      int xr[CPW];
+#pragma unroll
+      for (int q = 0; q < CPW; q++) {
+        xr[q] = 0;
+        curs[q] = __builtin_amdgcn_readfirstlane(curs[q]);  // uniform already; pins it to a scalar register
+      }
+      // a lane select written by a vector instruction needs four wait states,
+      // and nothing inserts them inside an asm statement
+      asm volatile("s_nop 3");
+      if (n == kChunk) {
+        // whole chunk: four steps per back-pointer dword, hand-written so that
+        // the walk stays on the scalar unit: record the lane, fetch that
+        // lane's dword, extract the step's byte (= the previous lane)
+        static_for<0, 16>([&](auto r_c) {
+          constexpr int i = 15 - decltype(r_c)::value;
+          // named references: operands of an asm statement alone do not make
+          // a generic lambda capture a variable
+          int &x0 = xr[0], &x1 = xr[CPW - 1], &c0 = curs[0], &c1 = curs[CPW - 1], &w0 = wtmp[0], &w1 = wtmp[1];
+          const uint32_t bpw = bpr[i];
+          if constexpr (CPW == 2) {
+            asm volatile(
+                "v_writelane_b32 %[x0], %[c0], %[t3]\n\tv_writelane_b32 %[x1], %[c1], %[t3]\n\t"
+                "v_readlane_b32 %[w0], %[bp], %[c0]\n\tv_readlane_b32 %[w1], %[bp], %[c1]\n\t"
+                "s_bfe_u32 %[c0], %[w0], 0x80018\n\ts_bfe_u32 %[c1], %[w1], 0x80018\n\ts_nop 1\n\t"
+                "v_writelane_b32 %[x0], %[c0], %[t2]\n\tv_writelane_b32 %[x1], %[c1], %[t2]\n\t"
+                "v_readlane_b32 %[w0], %[bp], %[c0]\n\tv_readlane_b32 %[w1], %[bp], %[c1]\n\t"
+                "s_bfe_u32 %[c0], %[w0], 0x80010\n\ts_bfe_u32 %[c1], %[w1], 0x80010\n\ts_nop 1\n\t"
+                "v_writelane_b32 %[x0], %[c0], %[t1]\n\tv_writelane_b32 %[x1], %[c1], %[t1]\n\t"
+                "v_readlane_b32 %[w0], %[bp], %[c0]\n\tv_readlane_b32 %[w1], %[bp], %[c1]\n\t"
+                "s_bfe_u32 %[c0], %[w0], 0x80008\n\ts_bfe_u32 %[c1], %[w1], 0x80008\n\ts_nop 1\n\t"
+                "v_writelane_b32 %[x0], %[c0], %[t0]\n\tv_writelane_b32 %[x1], %[c1], %[t0]\n\t"
+                "v_readlane_b32 %[w0], %[bp], %[c0]\n\tv_readlane_b32 %[w1], %[bp], %[c1]\n\t"
+                "s_bfe_u32 %[c0], %[w0], 0x80000\n\ts_bfe_u32 %[c1], %[w1], 0x80000\n\ts_nop 1"
+                : [x0] "+v"(x0), [x1] "+v"(x1), [c0] "+s"(c0), [c1] "+s"(c1), [w0] "=&s"(w0), [w1] "=&s"(w1)
+                : [bp] "v"(bpw), [t3] "n"(4 * i + 3), [t2] "n"(4 * i + 2), [t1] "n"(4 * i + 1), [t0] "n"(4 * i));
+          } else {
+            asm volatile(
+                "v_writelane_b32 %[x0], %[c0], %[t3]\n\tv_readlane_b32 %[w0], %[bp], %[c0]\n\t"
+                "s_bfe_u32 %[c0], %[w0], 0x80018\n\ts_nop 3\n\t"
+                "v_writelane_b32 %[x0], %[c0], %[t2]\n\tv_readlane_b32 %[w0], %[bp], %[c0]\n\t"
+                "s_bfe_u32 %[c0], %[w0], 0x80010\n\ts_nop 3\n\t"
+                "v_writelane_b32 %[x0], %[c0], %[t1]\n\tv_readlane_b32 %[w0], %[bp], %[c0]\n\t"
+                "s_bfe_u32 %[c0], %[w0], 0x80008\n\ts_nop 3\n\t"
+                "v_writelane_b32 %[x0], %[c0], %[t0]\n\tv_readlane_b32 %[w0], %[bp], %[c0]\n\t"
+                "s_bfe_u32 %[c0], %[w0], 0x80000\n\ts_nop 3"
+                : [x0] "+v"(x0), [c0] "+s"(c0), [w0] "=&s"(w0)
+                : [bp] "v"(bpw), [t3] "n"(4 * i + 3), [t2] "n"(4 * i + 2), [t1] "n"(4 * i + 1), [t0] "n"(4 * i));
+          }
+        });
+      } else {
+        static_for<0, kChunk>([&](auto r_c) {
+          constexpr int tt = kChunk - 1 - decltype(r_c)::value;
+          if (tt < n) {
+#pragma unroll
+            for (int q = 0; q < CPW; q++) {
+              const int cu = __builtin_amdgcn_readfirstlane(curs[q]);  // already uniform: keeps it scalar
+              asm("v_writelane_b32 %0, %1, %2" : "+v"(xr[q]) : "s"(cu), "n"(tt));
+              // at the chain's first node the value read is not used
+              const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)bpr[tt >> 2], cu);
+              curs[q] = (int)((w >> ((tt & 3) * 8)) & 0xffu);
+            }
+          }
+        });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // labels out, and this chunk's terms of the linear objective.  No
+      // divergent branch around the memory operations of a whole chunk, so
+      // that the wait for the next chunk's back-pointers can be a counted one
+      // and does not drain these gathers.
+#pragma unroll
+      for (int q = 0; q < CPW; q++) {
+        linc[q] += (double)gp[q];
+        linc[q] += (double)wp[q];
+        const int xi = xr[q] & (KP - 1);  // lane -> label
+        int xn = __shfl_down(xi, 1);
+        xn = (lane == n - 1) ? carry[q] : xn;
+        const int t = t0 + lane;
+        if (n == kChunk && cval[q]) {
+          xcb[q][t] = xi;
+          const float wv = args.Wsplit[xi * k + xn];
+          wp[q] = (t + 1 < T) ? wv : 0.0f;
+          gp[q] = (thb[q] + (size_t)(unsigned)t * nstride)[xi];
+        } else {
+          gp[q] = wp[q] = 0.0f;
+          if (lane < n) {
+            if (cval[q]) xcb[q][t] = xi;
+            if (t + 1 < T) wp[q] = args.Wsplit[xi * k + xn];
+            gp[q] = (thb[q] + (size_t)(unsigned)t * nstride)[xi];
+          }
+        }
+        carry[q] = __builtin_amdgcn_readlane(xi, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        bpr[i] = bpn[i];
+        bpn[i] = bpf[i];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < CPW; q++) {
+      double l = linc[q] + (double)gp[q] + (double)wp[q];
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) l += __shfl_xor(l, d);
+      if (cval[q] && lane == 0) sg.chain_lin[(wave - args.wave_begin[si]) * CPW + q] = l;
+    }
+    if (args.stamps && lane == 0) args.stamps[3 * (size_t)wave + 2] = __builtin_readcyclecounter();
+    return;
+  }
   constexpr int VW = DW >= 4 ? 4 : DW;  // dwords per load
   constexpr int NV = DW / VW;
   uint32_t stage[NV][VW];
@@ -458,13 +659,16 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     }
   };
   int cur = bi;
-  const int nchunks = Tpad / kChunk;
   // The chain's term of the linear objective (Grid.cpp:1665-1680): sum of
   // theta_share[x_t] + W[x_t][x_t+1] over the new labels, gathered chunk by
   // chunk by all lanes while lane 0 walks the next chunk.
   double lin = 0.0;
-  float gpend = 0.0f;  // gather of the previous chunk, still in flight
-  int carry = 0;       // label of the first node after the current chunk
+  constexpr int NI = kChunk / LPC;   // label positions per lane per chunk
+  constexpr bool DEFER = NI <= 4;    // consume a chunk's gathers one chunk later
+  float gp[DEFER ? NI : 1], wp[DEFER ? NI : 1];
+#pragma unroll
+  for (int q = 0; q < (DEFER ? NI : 1); q++) gp[q] = wp[q] = 0.0f;
+  int carry = 0;  // label of the first node after the current chunk
   fetch_chunk(nchunks - 1);
   for (int ci = nchunks - 1; ci >= 0; ci--) {
     const int t0 = ci * kChunk;
@@ -480,33 +684,66 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     if (ci > 0) fetch_chunk(ci - 1);
     if (within == 0) {
       const uint8_t *bytes = reinterpret_cast<const uint8_t *>(&s_bp[wib][cs][0]);
-      for (int tt = n - 1; tt >= 0; tt--) {
-        s_x[wib][cs][tt] = cur;
-        if (t0 + tt > 0) cur = bytes[(((tt >> 2) * KP + cur) << 2) + (tt & 3)];
+      if (n == kChunk && ci > 0) {
+        // whole chunk, not the chain's first: every offset but the label is static
+#pragma unroll
+        for (int tt = kChunk - 1; tt >= 0; tt--) {
+          s_x[wib][cs][tt] = cur;
+          cur = bytes[(cur << 2) + (((tt >> 2) * KP) << 2) + (tt & 3)];
+        }
+      } else {
+        for (int tt = n - 1; tt >= 0; tt--) {
+          s_x[wib][cs][tt] = cur;
+          if (t0 + tt > 0) cur = bytes[(((tt >> 2) * KP + cur) << 2) + (tt & 3)];
+        }
       }
     }
     cur = __shfl(cur, cs * LPC);
     wave_lds_fence();
-    lin += (double)gpend;
-    gpend = 0.0f;
-    for (int i = within; i < n; i += LPC) {
-      const int xi = s_x[wib][cs][i];
-      if (cvalid) xchain[t0 + i] = xi;
-      const int t = t0 + i;
-      if (t + 1 < T) {
-        const int xn = (i + 1 < n) ? s_x[wib][cs][i + 1] : carry;
-        lin += (double)args.Wsplit[xi * k + xn];
+    if (DEFER) {
+#pragma unroll
+      for (int q = 0; q < NI; q++) {
+        lin += (double)gp[q];
+        lin += (double)wp[q];
+        gp[q] = wp[q] = 0.0f;
       }
-      const float g = (th_c + (size_t)(unsigned)t * nstride)[xi];
-      if (LPC >= kChunk) gpend = g; else lin += (double)g;
+    }
+#pragma unroll
+    for (int q = 0; q < NI; q++) {
+      const int i = within + q * LPC;
+      if (i < n) {
+        const int xi = s_x[wib][cs][i];
+        if (cvalid) xchain[t0 + i] = xi;
+        const int t = t0 + i;
+        float wv = 0.0f;
+        if (t + 1 < T) {
+          const int xn = (i + 1 < n) ? s_x[wib][cs][i + 1] : carry;
+          wv = args.Wsplit[xi * k + xn];
+        }
+        const float g = (th_c + (size_t)(unsigned)t * nstride)[xi];
+        if (DEFER) {
+          gp[q] = g;
+          wp[q] = wv;
+        } else {
+          lin += (double)g;
+          lin += (double)wv;
+        }
+      }
     }
     carry = s_x[wib][cs][0];
     wave_lds_fence();
   }
-  lin += (double)gpend;
+  if (DEFER) {
+#pragma unroll
+    for (int q = 0; q < NI; q++) {
+      lin += (double)gp[q];
+      lin += (double)wp[q];
+    }
+  }
 #pragma unroll
   for (int d = 1; d < LPC; d <<= 1) lin += __shfl_xor(lin, d);
   if (cvalid && within == 0) sg.chain_lin[chain] = lin;
+  if (args.stamps && lane == 0) args.stamps[3 * (size_t)wave + 2] = __builtin_readcyclecounter();
 }
 
 // Consensus of a strip of nr x nc nodes from the two label arrays:
