@@ -66,8 +66,14 @@ struct admm_ctx {
   uint8_t *bp_r = nullptr, *bp_c = nullptr;
   float *d_W = nullptr, *d_Wsplit = nullptr, *d_Wt = nullptr;
   float *d_chain_min = nullptr;
-  double *d_chain_lin = nullptr;  // per chain: its term of the linear objective (written by Compute)
+  // The linear objective of a solve has two per-chain terms: the pairwise one
+  // is written by that solve's sweep, the unary one by the NEXT sweep (which
+  // has the operands in registers) or, when somebody asks before that, by a
+  // gather kernel.
+  double *d_chain_lin = nullptr;    // per chain: pairwise energy of its new labels (written by Compute)
+  double *d_chain_unary = nullptr;  // per chain: unary energy of the labels the last sweep started from
   bool lin_valid = false;
+  int pending_slot = 0;             // queued objective whose unary term is still to come, or 0
   int *sendbuf = nullptr;
   std::vector<float> h_unary_stage;
 
@@ -203,6 +209,7 @@ void fill_seg_rows(const admm_ctx *c, ChainSeg &s, bool dual) {
   s.theta = c->th_r; s.lam = c->lam_r; s.x = c->xrow_r; s.xo = c->xo_r; s.bp = c->bp_r;
   s.chain_min = dual ? c->d_chain_min : nullptr;
   s.chain_lin = c->d_chain_lin;
+  s.chain_unary = c->d_chain_unary;
   s.nchains = d.batch * c->st.nrows;
   s.T = d.cols;
   s.cpg = std::max(1, c->st.nrows);
@@ -216,6 +223,7 @@ void fill_seg_cols(const admm_ctx *c, ChainSeg &s, bool dual) {
   s.theta = c->th_c; s.lam = c->lam_c; s.x = c->xcolT_c; s.xo = c->xo_c; s.bp = c->bp_c;
   s.chain_min = dual ? c->d_chain_min + (long long)d.batch * c->st.nrows : nullptr;
   s.chain_lin = c->d_chain_lin + (long long)d.batch * c->st.nrows;
+  s.chain_unary = c->d_chain_unary + (long long)d.batch * c->st.nrows;
   s.nchains = d.batch * c->st.ncols;
   s.T = d.rows;
   s.cpg = std::max(1, c->st.ncols);
@@ -345,6 +353,9 @@ int check_ctx(admm_ctx *c) {
 }  // namespace
 
 // ====================================================================== C ABI
+
+static int flush_pending(admm_ctx *c);
+static int chain_unary_from_sweep(admm_ctx *c, double *slot);
 
 extern "C" {
 
@@ -485,7 +496,8 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
         (rc = dev_alloc(c, &c->d_W, k * k)) || (rc = dev_alloc(c, &c->d_Wsplit, k * k)) ||
         (rc = dev_alloc(c, &c->d_Wt, k * k)) ||
         (rc = dev_alloc(c, &c->d_chain_min, B * ((size_t)c->st.nrows + c->st.ncols))) ||
-        (rc = dev_alloc(c, &c->d_chain_lin, B * ((size_t)c->st.nrows + c->st.ncols))))
+        (rc = dev_alloc(c, &c->d_chain_lin, B * ((size_t)c->st.nrows + c->st.ncols))) ||
+        (rc = dev_alloc(c, &c->d_chain_unary, B * ((size_t)c->st.nrows + c->st.ncols))))
       return bail(rc);
     HIP_TRY_BAIL(hipMemset(c->th_r + nrow_nodes * k, 0, sizeof(float) * slack));
     HIP_TRY_BAIL(hipMemset(c->lam_r + nrow_nodes * k, 0, sizeof(float) * slack));
@@ -535,6 +547,7 @@ int admm_upload_unaries(admm_ctx *c, const float *unary) {
   int rc = check_ctx(c);
   if (rc) return rc;
   if (!unary) return fail(c, ADMM_E_ARG, "null unary array");
+  if ((rc = flush_pending(c))) return rc;  // a queued objective still needs the old unaries
   const size_t k = c->d.k;
   if (!is_chain(c)) {
     HIP_TRY(c, hipMemcpyAsync(c->d_vert_pot, unary, sizeof(float) * (size_t)c->V * k, hipMemcpyHostToDevice, c->stream));
@@ -610,6 +623,7 @@ int admm_init(admm_ctx *c) {
   int rc = check_ctx(c);
   if (rc) return rc;
   if (!c->have_unary || !c->have_pair) return fail(c, ADMM_E_STATE, "upload unaries and the pairwise table before admm_init");
+  if ((rc = flush_pending(c))) return rc;  // a queued objective still needs the old labels
   const admm_desc &d = c->d;
   hipStream_t s = c->stream;
   if (!is_chain(c)) {
@@ -667,6 +681,13 @@ int admm_compute(admm_ctx *c) {
   }
   rc = is_chain(c) ? chain_sweep(c, false) : edge_compute(c);
   if (rc) return rc;
+  if (is_chain(c) && c->pending_slot) {
+    // this sweep summed the unaries of the labels it started from: the
+    // missing term of the objective queued for the previous solve
+    const int slot = c->pending_slot;
+    c->pending_slot = 0;
+    if ((rc = chain_unary_from_sweep(c, c->d_obj_slots + 2 * (size_t)slot))) return rc;
+  }
   c->lin_valid = true;
   if (c->prof) HIP_TRY(c, hipEventRecord(e1, c->stream));
   return ADMM_OK;
@@ -890,16 +911,17 @@ __global__ __launch_bounds__(256) void objective_reduce_kernel(double *__restric
 }  // namespace
 
 namespace {
-// dst[1] = sum of the per-chain linear terms; dst[0] is left alone.
+// dst[0] = sum of part[i * stride], i < n (+ the old dst[0] when accumulate).
 __global__ __launch_bounds__(256) void linear_reduce_kernel(double *__restrict__ dst,
-                                                            const double *__restrict__ part, int n) {
+                                                            const double *__restrict__ part, int n,
+                                                            int stride, int accumulate) {
   __shared__ double s_red[4];
   double l = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) l += part[i];
+  for (int i = threadIdx.x; i < n; i += 256) l += part[(size_t)i * stride];
   l = wave_sum(l);
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = l;
   __syncthreads();
-  if (threadIdx.x == 0) dst[1] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  if (threadIdx.x == 0) dst[0] = (accumulate ? dst[0] : 0.0) + s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
 }  // namespace
 
@@ -936,12 +958,53 @@ static int chain_obj_partials(admm_ctx *c, double *primal, double *linear) {
   return ADMM_OK;
 }
 
-static int chain_linear_enqueue(admm_ctx *c, double *dst) {
-  // After a Compute the sweep has left every chain's term in d_chain_lin.
+// A queued or returned linear objective is slot[0] + slot[1]: the unary and
+// the pairwise energy of every chain's own labels (Grid.cpp:1665-1680).
+
+// slot[1] = pairwise term; the last sweep left it per chain in d_chain_lin.
+static int chain_pairwise_enqueue(admm_ctx *c, double *slot) {
   const int n = c->d.batch * (c->st.nrows + c->st.ncols);
-  hipLaunchKernelGGL(linear_reduce_kernel, dim3(1), dim3(256), 0, c->stream, dst, c->d_chain_lin, n);
+  hipLaunchKernelGGL(linear_reduce_kernel, dim3(1), dim3(256), 0, c->stream, slot + 1, c->d_chain_lin, n, 1, 0);
   HIP_TRY(c, hipGetLastError());
   return ADMM_OK;
+}
+
+// slot[0] = unary term of the labels the last sweep started from (it left
+// them per chain in d_chain_unary).
+static int chain_unary_from_sweep(admm_ctx *c, double *slot) {
+  const int n = c->d.batch * (c->st.nrows + c->st.ncols);
+  hipLaunchKernelGGL(linear_reduce_kernel, dim3(1), dim3(256), 0, c->stream, slot, c->d_chain_unary, n, 1, 0);
+  HIP_TRY(c, hipGetLastError());
+  return ADMM_OK;
+}
+
+// slot[0] = unary term of the current labels, gathered now.
+static int chain_unary_gather(admm_ctx *c, double *slot) {
+  hipStream_t s = c->stream;
+  int pass = 0;
+  for (int seg = 0; seg < 2; seg++) {
+    ChainSeg sg{};
+    if (seg == 0) fill_seg_rows(c, sg, false); else fill_seg_cols(c, sg, false);
+    const long long total = (long long)sg.nchains * sg.T;
+    if (total <= 0) continue;
+    const int blocks = (int)std::min<long long>(c->n_partial, (total + 255) / 256);
+    hipLaunchKernelGGL(chain_objective_kernel, dim3(blocks), dim3(256), 0, s, c->d_partial, sg.theta, c->d_Wsplit,
+                       sg.x, sg.xo, sg.nchains, sg.T, sg.cpg, sg.gstride, sg.cstride, sg.sstride, c->d.k, 2);
+    hipLaunchKernelGGL(linear_reduce_kernel, dim3(1), dim3(256), 0, s, slot, c->d_partial + 1, blocks, 2, pass);
+    HIP_TRY(c, hipGetLastError());
+    pass++;
+  }
+  if (pass == 0) HIP_TRY(c, hipMemsetAsync(slot, 0, sizeof(double), s));
+  return ADMM_OK;
+}
+
+// Completes the queued objective that still waits for its unary term.  Must
+// run before anything changes the labels or the unaries.
+static int flush_pending(admm_ctx *c) {
+  if (!c->pending_slot) return ADMM_OK;
+  const int slot = c->pending_slot;
+  c->pending_slot = 0;
+  return chain_unary_gather(c, c->d_obj_slots + 2 * (size_t)slot);
 }
 
 int admm_linear_objective(admm_ctx *c, double *obj) {
@@ -951,11 +1014,11 @@ int admm_linear_objective(admm_ctx *c, double *obj) {
   if (!obj) return fail(c, ADMM_E_ARG, "null output");
   if (is_chain(c)) {
     if (!c->lin_valid) return chain_obj_partials(c, nullptr, obj);  // before the first Compute
-    if ((rc = chain_linear_enqueue(c, c->d_obj_slots))) return rc;
+    if ((rc = chain_pairwise_enqueue(c, c->d_obj_slots)) || (rc = chain_unary_gather(c, c->d_obj_slots))) return rc;
     double h[2];
     HIP_TRY(c, hipMemcpyAsync(h, c->d_obj_slots, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    *obj = h[1] * c->d.rho;
+    *obj = (h[0] + h[1]) * c->d.rho;
     return ADMM_OK;
   }
   const long long nn = (long long)c->E * 2 * c->d.k, ne = (long long)c->E * c->d.k * c->d.k;
@@ -1001,7 +1064,10 @@ int admm_objective_enqueue(admm_ctx *c, int slot) {
   if (!is_chain(c)) return fail(c, ADMM_E_STATE, "queued objectives are a chain-solver feature");
   if (slot < 1 || slot >= c->n_obj_slots) return fail(c, ADMM_E_ARG, "slot must be in [1, %d)", c->n_obj_slots);
   if (!c->lin_valid) return fail(c, ADMM_E_STATE, "admm_objective_enqueue needs a preceding admm_compute");
-  return chain_linear_enqueue(c, c->d_obj_slots + 2 * (size_t)slot);
+  if ((rc = flush_pending(c))) return rc;  // two requests for the same solve
+  if ((rc = chain_pairwise_enqueue(c, c->d_obj_slots + 2 * (size_t)slot))) return rc;
+  c->pending_slot = slot;  // the next sweep (or a read before it) supplies the unary term
+  return ADMM_OK;
 }
 
 int admm_objective_read(admm_ctx *c, int slot, int n, double *linear) {
@@ -1009,11 +1075,12 @@ int admm_objective_read(admm_ctx *c, int slot, int n, double *linear) {
   if (rc) return rc;
   if (!is_chain(c)) return fail(c, ADMM_E_STATE, "queued objectives are a chain-solver feature");
   if (slot < 1 || n < 0 || slot + n > c->n_obj_slots) return fail(c, ADMM_E_ARG, "slot range out of bounds");
+  if (c->pending_slot >= slot && c->pending_slot < slot + n && (rc = flush_pending(c))) return rc;
   std::vector<double> h(2 * (size_t)n);
   HIP_TRY(c, hipMemcpyAsync(h.data(), c->d_obj_slots + 2 * (size_t)slot, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < n; i++)
-    if (linear) linear[i] = h[2 * i + 1] * c->d.rho;
+    if (linear) linear[i] = (h[2 * i] + h[2 * i + 1]) * c->d.rho;
   return ADMM_OK;
 }
 

@@ -37,7 +37,8 @@ struct ChainSeg {
   const int *xo;       // [nchains][T] labels the crossing chains gave the same nodes
   uint8_t *bp;         // [nchains][T][KP] back-pointer scratch
   float *chain_min;    // [nchains] (dual evaluation only)
-  double *chain_lin;   // [nchains] energy of the chain's new labels under its own share
+  double *chain_lin;   // [nchains] pairwise energy of the chain's new labels: sum of (W / rho)[x_t][x_t+1]
+  double *chain_unary; // [nchains] unary energy of the labels the sweep started from: sum of theta_share[x_t]
   int nchains;
   int T;
   int cpg;
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   }
 
   uint32_t acc = 0, keep = 0;
+  double unary_acc = 0.0;
 
   // Software pipeline: the back-pointer of a step (which source attained the
   // minimum) is not needed to go on, only the minimum is.  So a step's
@@ -265,20 +267,34 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // the block that starts at step tbp.  live = false: the step lies past the
   // chain's end and only the packing goes on, so a partly filled window of
   // four steps is still stored.
+  // With the group scheme the arg-min has two stages, one step apart, so that
+  // the LDS reads of the first are never waited for: locate() finds the group
+  // and issues the reads of its four candidates, finish() compares them.
+  typedef float f4_t __attribute__((ext_vector_type(4)));
+  f4_t m4_pend = {0.f, 0.f, 0.f, 0.f}, w4_pend = {0.f, 0.f, 0.f, 0.f};
+  int grp_pend = 0;
+  float best_pend = 0.0f;
+  auto locate = [&](auto sbp_c, const bool live) {
+    constexpr int SBP = decltype(sbp_c)::value;
+    if constexpr (RECOMP) {
+      if (live) {
+        grp_pend = first_equal<NG>(c_prev, best_prev);
+        best_pend = best_prev;
+        // the step's messages are still in the row it read them from
+        m4_pend = *reinterpret_cast<const f4_t *>(&s_M[wib][(SBP & 1) * MROW + cs * KP + 4 * grp_pend]);
+        w4_pend = *reinterpret_cast<const f4_t *>(&s_W[b * WLD + 4 * grp_pend]);
+      }
+    }
+  };
   auto finish = [&](auto sbp_c, const int tbp, const bool live) {
     constexpr int SBP = decltype(sbp_c)::value;
     if (DUAL) return;
     int arg = 0;
     if (live) {
       if constexpr (RECOMP) {
-        typedef float f4 __attribute__((ext_vector_type(4)));
-        const int grp = first_equal<NG>(c_prev, best_prev);
-        // the step's messages are still in the row it read them from
-        const f4 m4 = *reinterpret_cast<const f4 *>(&s_M[wib][(SBP & 1) * MROW + cs * KP + 4 * grp]);
-        const f4 w4 = *reinterpret_cast<const f4 *>(&s_W[b * WLD + 4 * grp]);
-        const f4 c4 = m4 + w4;
+        const f4_t c4 = m4_pend + w4_pend;
         const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
-        arg = 4 * grp + first_equal<4>(cc, best_prev);
+        arg = 4 * grp_pend + first_equal<4>(cc, best_pend);
       } else {
         arg = s * A + first_equal<A>(c_prev, best_prev);
       }
@@ -336,6 +352,10 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       } else if (glive) {
         // p = penalty * (mu - m) = -(penalty * (m - mu)), exactly
         const float p = ((xown == b) ? hpen : 0.0f) - ((xoth == b) ? hpen : 0.0f);
+        // Unary energy of the labels this sweep starts from (one of the two
+        // terms of Grid.cpp:1665-1680 for the previous solve): the operand is
+        // in a register here, which saves the backtrack a gather per node.
+        unary_acc += (xown == b) ? (double)th_in : 0.0;
         const float la = lam_in + p;                          // Tree.cpp:70
         if (lvalid && (FULL || tg + s < T)) (lam_c + goff)[lane_off] = la;
         th_own = rho * (th_in + la) + p;                      // Tree.cpp:85-86
@@ -370,7 +390,16 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         }
         __builtin_amdgcn_sched_barrier(0);
         // (b) ... while the previous step's back-pointer is worked out
-        if constexpr (PIPE) {
+        if constexpr (RECOMP) {
+          // compare for the step two back, then locate for the step one back
+          constexpr int P = j * NS + u;
+          constexpr int Q2 = (P + BLK - 2) % BLK, Q1 = (P + BLK - 1) % BLK;
+          if (P >= 2) finish(std::integral_constant<int, Q2>{}, tb, FULL || tb + Q2 < T);
+          else if (tb > 0) finish(std::integral_constant<int, Q2>{}, tb - BLK, true);
+          if (P >= 1) locate(std::integral_constant<int, Q1>{}, FULL || tb + Q1 < T);
+          else if (tb > 0) locate(std::integral_constant<int, Q1>{}, true);
+          __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (PIPE) {
           if (j == 0 && u == 0) {
             if (tb > 0) finish(std::integral_constant<int, BLK - 1>{}, tb - BLK, true);
           } else {
@@ -461,6 +490,10 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // the last block's final position is still pending
   if (!DUAL && PIPE) {
     const int tb_last = ((T - 1) / BLK) * BLK;
+    if constexpr (RECOMP) {
+      finish(std::integral_constant<int, BLK - 2>{}, tb_last, tb_last + BLK - 2 < T);
+      locate(std::integral_constant<int, BLK - 1>{}, tb_last + BLK - 1 < T);
+    }
     finish(std::integral_constant<int, BLK - 1>{}, tb_last, tb_last + BLK - 1 < T);
   }
 
@@ -481,6 +514,9 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     return;
   }
 
+#pragma unroll
+  for (int d = 1; d < LPC; d <<= 1) unary_acc += __shfl_xor(unary_acc, d);
+  if (cvalid && within == 0) sg.chain_unary[chain] = unary_acc;
   if (args.stamps && lane == 0) {
     args.stamps[3 * (size_t)wave] = st0;
     args.stamps[3 * (size_t)wave + 1] = __builtin_readcyclecounter();
@@ -503,21 +539,18 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     };
     int curs[CPW], carry[CPW], wtmp[2] = {0, 0};
     double linc[CPW];
-    float gp[CPW], wp[CPW];
-    const float *thb[CPW];  // uniform base pointers of the chains of this wavefront
-    int *xcb[CPW];
+    float wp[CPW];
+    int *xcb[CPW];  // uniform base pointers of the chains of this wavefront
     bool cval[CPW];
 #pragma unroll
     for (int q = 0; q < CPW; q++) {
       curs[q] = q * LPC + __builtin_amdgcn_readlane(bi, q * LPC);  // lane holding the chain's last label
       carry[q] = 0;
       linc[q] = 0.0;
-      gp[q] = wp[q] = 0.0f;
+      wp[q] = 0.0f;
       const int craw = (wave - args.wave_begin[si]) * CPW + q;
       cval[q] = craw < sg.nchains;
       const int cq = cval[q] ? craw : sg.nchains - 1;
-      const long long fq = (long long)(cq / sg.cpg) * sg.gstride + (long long)(cq % sg.cpg) * sg.cstride;
-      thb[q] = sg.theta + fq * k;
       xcb[q] = sg.x + (long long)cq * T;
     }
     // back-pointers are fetched two chunks ahead of the walk (bpr: this chunk,
@@ -602,7 +635,6 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       // and does not drain these gathers.
 #pragma unroll
       for (int q = 0; q < CPW; q++) {
-        linc[q] += (double)gp[q];
         linc[q] += (double)wp[q];
         const int xi = xr[q] & (KP - 1);  // lane -> label
         int xn = __shfl_down(xi, 1);
@@ -612,13 +644,11 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
           xcb[q][t] = xi;
           const float wv = args.Wsplit[xi * k + xn];
           wp[q] = (t + 1 < T) ? wv : 0.0f;
-          gp[q] = (thb[q] + (size_t)(unsigned)t * nstride)[xi];
         } else {
-          gp[q] = wp[q] = 0.0f;
+          wp[q] = 0.0f;
           if (lane < n) {
             if (cval[q]) xcb[q][t] = xi;
             if (t + 1 < T) wp[q] = args.Wsplit[xi * k + xn];
-            gp[q] = (thb[q] + (size_t)(unsigned)t * nstride)[xi];
           }
         }
         carry[q] = __builtin_amdgcn_readlane(xi, 0);
@@ -631,7 +661,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     }
 #pragma unroll
     for (int q = 0; q < CPW; q++) {
-      double l = linc[q] + (double)gp[q] + (double)wp[q];
+      double l = linc[q] + (double)wp[q];
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) l += __shfl_xor(l, d);
       if (cval[q] && lane == 0) sg.chain_lin[(wave - args.wave_begin[si]) * CPW + q] = l;
@@ -659,15 +689,14 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     }
   };
   int cur = bi;
-  // The chain's term of the linear objective (Grid.cpp:1665-1680): sum of
-  // theta_share[x_t] + W[x_t][x_t+1] over the new labels, gathered chunk by
-  // chunk by all lanes while lane 0 walks the next chunk.
+  // The pairwise term of the chain's energy (Grid.cpp:1665-1680): sum of
+  // W[x_t][x_t+1] over the new labels, gathered chunk by chunk by all lanes.
   double lin = 0.0;
   constexpr int NI = kChunk / LPC;   // label positions per lane per chunk
   constexpr bool DEFER = NI <= 4;    // consume a chunk's gathers one chunk later
-  float gp[DEFER ? NI : 1], wp[DEFER ? NI : 1];
+  float wp[DEFER ? NI : 1];
 #pragma unroll
-  for (int q = 0; q < (DEFER ? NI : 1); q++) gp[q] = wp[q] = 0.0f;
+  for (int q = 0; q < (DEFER ? NI : 1); q++) wp[q] = 0.0f;
   int carry = 0;  // label of the first node after the current chunk
   fetch_chunk(nchunks - 1);
   for (int ci = nchunks - 1; ci >= 0; ci--) {
@@ -703,9 +732,8 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     if (DEFER) {
 #pragma unroll
       for (int q = 0; q < NI; q++) {
-        lin += (double)gp[q];
         lin += (double)wp[q];
-        gp[q] = wp[q] = 0.0f;
+        wp[q] = 0.0f;
       }
     }
 #pragma unroll
@@ -720,14 +748,8 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
           const int xn = (i + 1 < n) ? s_x[wib][cs][i + 1] : carry;
           wv = args.Wsplit[xi * k + xn];
         }
-        const float g = (th_c + (size_t)(unsigned)t * nstride)[xi];
-        if (DEFER) {
-          gp[q] = g;
-          wp[q] = wv;
-        } else {
-          lin += (double)g;
-          lin += (double)wv;
-        }
+        if (DEFER) wp[q] = wv;
+        else lin += (double)wv;
       }
     }
     carry = s_x[wib][cs][0];
@@ -736,7 +758,6 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   if (DEFER) {
 #pragma unroll
     for (int q = 0; q < NI; q++) {
-      lin += (double)gp[q];
       lin += (double)wp[q];
     }
   }
@@ -820,6 +841,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // chains gave the same nodes).  d = decoded label = argmax of the consensus.
 //   primal += [mode & 1] 2 * theta_share[d]  +  W[d][d_next]
 //   linear +=            theta_share[x_own]  +  W[x_own][x_own_next]
+// mode & 2: only linear += theta_share[x_own] (primal untouched).
 // "next" is the next node along the chain.  The row chains are run with
 // mode 1 and the column chains with mode 0, so every unary and every edge is
 // counted once.  linear is the chain analogue of Grid.cpp:1665-1680 (every
@@ -842,6 +864,10 @@ __global__ __launch_bounds__(256) void chain_objective_kernel(
     const int xo0 = xo < 0 ? 0 : xo;
     const long long node = (long long)(chain / cpg) * gstride + (long long)(chain % cpg) * cstride + (long long)t * sstride;
     const float *th = theta + node * k;
+    if (mode & 2) {  // unary term of the chains' own labels only
+      lin += (double)th[xo0];
+      continue;
+    }
     if (mode & 1) {
       p += (double)th[d];
       p += (double)th[d];

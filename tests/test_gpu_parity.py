@@ -194,16 +194,48 @@ def test_chain_strips_equal_single_strip(G, R, C, k, pw):
 
 
 def test_chain_queued_objectives_match_blocking_calls():
+    """A queued objective gets its unary term from the next sweep, or from a gather when it
+    is read (or queued again) before that; either way it equals the blocking call."""
     from oracle import oracle as O
     R, C, k = 30, 45, 16
     un, W = O.synth_problem(R, C, k, 5, "trunc_linear")
+    o = O.ChainOracle(R, C, k, un, W); o.init()
     g = _chain_grid(R, C, k, un, W)
-    blocking = []
+    blocking, ref = [], []
     for it in range(7):
+        _step(g)
+        o.compute(); o.update()
+        ref.append(o.objective()[2])
+        g.ObjectiveEnqueue(1 + it)
+        if it == 2:
+            g.ObjectiveEnqueue(20)   # the same solve queued twice
+        if it == 4:                  # read while the unary term is still outstanding
+            assert abs(g.ObjectiveRead(5, 1)[0] - ref[-1]) <= OBJ_RTOL * abs(ref[-1])
+        if it % 2 == 0:
+            blocking.append(g.ComputeLinearObj())
+            assert abs(blocking[-1] - ref[-1]) <= OBJ_RTOL * abs(ref[-1])
+    q = g.ObjectiveRead(1, 7)        # the last one is completed by the read
+    assert np.all(np.abs(q - np.array(ref)) <= OBJ_RTOL * np.abs(ref))
+    assert abs(g.ObjectiveRead(20, 1)[0] - ref[2]) <= OBJ_RTOL * abs(ref[2])
+    g.close()
+
+
+@pytest.mark.parametrize("R,C,k,pw,B", [(70, 65, 32, "potts", 1), (20, 67, 64, "dense", 1), (33, 70, 8, "potts", 3),
+                                        (9, 200, 5, "dense", 1), (40, 130, 16, "trunc_linear", 1)])
+def test_chain_queued_objective_every_lane_layout(R, C, k, pw, B):
+    """The sweep's own unary sums (every lane layout, ragged sizes, a batch) against the gather."""
+    from oracle import oracle as O
+    W = O.pairwise_table(pw, k, 99) if pw == "dense" else O.pairwise_table(pw, k)
+    un = np.concatenate([O.lcg_fill(77 + b, R * C * k)[0] for b in range(B)])
+    g = _chain_grid(R, C, k, un, W, batch=B)
+    blocking = []
+    for it in range(4):
         _step(g)
         g.ObjectiveEnqueue(1 + it)
         blocking.append(g.ComputeLinearObj())
-    assert np.array_equal(g.ObjectiveRead(1, 7), np.array(blocking))
+    _step(g)                         # supplies the fourth unary term
+    q = g.ObjectiveRead(1, 4)
+    assert np.all(np.abs(q - np.array(blocking)) <= OBJ_RTOL * np.abs(blocking))
     g.close()
 
 
