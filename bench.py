@@ -75,6 +75,24 @@ def cpu_baseline(rows, cols, k, pairwise, seed, seconds_budget=25.0):
     }
 
 
+def measured_traffic(workload, world):
+    """HBM bytes per sweep launch from the committed counter passes (FETCH_SIZE
+    and WRITE_SIZE cannot be collected from inside this process), or None when
+    no pass covers this workload."""
+    import glob
+    if world != 1:
+        return None, None
+    here = os.path.dirname(os.path.abspath(__file__))
+    for f in sorted(glob.glob(os.path.join(here, "profiles", "r*_hbm_traffic_sweep.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if str(d.get("workload", "")).startswith(workload):
+            return d.get("hbm_bytes_per_launch"), "profiles/" + os.path.basename(f)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,6 +218,7 @@ def main():
 
     out = None
     if rank == 0:
+        traffic, traffic_src = measured_traffic(args.workload, world)
         out = {
             "metric": "admm_iterations_per_sec",
             "value": it_per_s,
@@ -228,7 +247,7 @@ def main():
                 "kernel": "chain_sweep_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "bytes_per_launch": sweep_b, "ms_per_launch": sweep_ms, "launches_timed": launches,
-                "traffic": None,
+                "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
