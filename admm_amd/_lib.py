@@ -50,7 +50,10 @@ def _load():
         raise ImportError(
             "%s is missing: build it with `make -C admm_amd/csrc` (hipcc, gfx950). "
             "There is no CPU fallback." % LIB_PATH)
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    # Default (local) binding on purpose: with RTLD_GLOBAL the HIP runtime and
+    # RCCL this library brings in would also serve a later `import torch`,
+    # which carries its own copies, and the mix aborts at exit.
+    lib = C.CDLL(LIB_PATH)
     fp, ip, dp, vp = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_void_p
     sig = {
         "admm_create": (C.c_int, [C.POINTER(AdmmDesc), C.POINTER(vp)]),

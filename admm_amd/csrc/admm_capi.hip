@@ -75,6 +75,7 @@ struct admm_ctx {
   bool lin_valid = false;
   int pending_slot = 0;             // queued objective whose unary term is still to come, or 0
   int *sendbuf = nullptr;
+  float *sendbuf_mu = nullptr, *recvbuf_mu = nullptr;  // ADMM_EXCHANGE_DENSE: the same blocks as float k-vectors
   std::vector<float> h_unary_stage;
 
   ncclComm_t comm = nullptr;
@@ -509,6 +510,10 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
           (rc = dev_alloc(c, &c->xrow_c, ncol_nodes)) || (rc = dev_alloc(c, &c->xcolT_r, nrow_nodes)) ||
           (rc = dev_alloc(c, &c->sendbuf, nrow_nodes + ncol_nodes)))
         return bail(rc);
+      if (d.exchange == ADMM_EXCHANGE_DENSE &&
+          ((rc = dev_alloc(c, &c->sendbuf_mu, (nrow_nodes + ncol_nodes) * k)) ||
+           (rc = dev_alloc(c, &c->recvbuf_mu, (nrow_nodes + ncol_nodes) * k))))
+        return bail(rc);
       HIP_TRY_BAIL(hipMemset(c->th_c + ncol_nodes * k, 0, sizeof(float) * slack));
     }
     c->n_partial = 2048;
@@ -733,6 +738,57 @@ int pack_labels(admm_ctx *c, const ExchangePlan &p) {
       hipLaunchKernelGGL(label_block_copy_kernel, dim3(grid_for((long long)nc * p.nr[h], 256)), dim3(256), 0, c->stream,
                          send_b + p.off_b[h], (long long)p.nr[h], c->xcolT_c + p.r0[h], (long long)d.rows, nc, p.nr[h]);
   }
+  if (d.exchange == ADMM_EXCHANGE_DENSE) {
+    const long long n = p.off_a[d.nranks] + p.off_b[d.nranks];
+    if (n > 0)
+      hipLaunchKernelGGL(labels_to_marginals_kernel, dim3(grid_for(n * d.k, 256)), dim3(256), 0, c->stream,
+                         c->sendbuf_mu, c->sendbuf, n, d.k, c->inv_k);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return ADMM_OK;
+}
+
+// What goes over the wire, in 4-byte elements: labels, or their marginals
+// (k floats per label) in the dense mode.  Receive side: region a = the peers'
+// row-chain results on my columns ([rows][nc]), region b = their column-chain
+// results on my rows ([cols][nr]); in the dense mode both are staged in
+// recvbuf_mu and turned back into labels by unpack_received().
+struct Wire {
+  int m;               // elements per label
+  const int32_t *send; // packed blocks
+  int32_t *recv_a, *recv_b;
+};
+
+Wire wire_of(admm_ctx *c) {
+  const admm_desc &d = c->d;
+  Wire w;
+  if (d.exchange == ADMM_EXCHANGE_DENSE) {
+    w.m = d.k;
+    w.send = reinterpret_cast<const int32_t *>(c->sendbuf_mu);
+    w.recv_a = reinterpret_cast<int32_t *>(c->recvbuf_mu);
+    w.recv_b = reinterpret_cast<int32_t *>(c->recvbuf_mu + (size_t)d.rows * c->st.ncols * d.k);
+  } else {
+    w.m = 1;
+    w.send = c->sendbuf;
+    w.recv_a = c->xrow_c;
+    w.recv_b = c->xcolT_r;
+  }
+  return w;
+}
+
+int unpack_received(admm_ctx *c) {
+  const admm_desc &d = c->d;
+  if (d.exchange != ADMM_EXCHANGE_DENSE) return ADMM_OK;
+  // Before the first solve every copy is uniform and every label is -1 on
+  // every strip already.
+  if (!c->lin_valid) return ADMM_OK;
+  const long long na = (long long)d.rows * c->st.ncols, nb = (long long)d.cols * c->st.nrows;
+  if (na > 0)
+    hipLaunchKernelGGL(marginals_to_labels_kernel, dim3(grid_for(na, 256)), dim3(256), 0, c->stream, c->xrow_c,
+                       c->recvbuf_mu, na, d.k);
+  if (nb > 0)
+    hipLaunchKernelGGL(marginals_to_labels_kernel, dim3(grid_for(nb, 256)), dim3(256), 0, c->stream, c->xcolT_r,
+                       c->recvbuf_mu + (size_t)na * d.k, nb, d.k);
   HIP_TRY(c, hipGetLastError());
   return ADMM_OK;
 }
@@ -751,18 +807,21 @@ int admm_communicate(admm_ctx *c) {
   const int nr = c->st.nrows, nc = c->st.ncols;
   const ExchangePlan p = make_plan(c);
   if ((rc = pack_labels(c, p))) return rc;
-  int *send_a = c->sendbuf, *send_b = c->sendbuf + p.off_a[G];
-  // Both kinds of block arrive contiguous on the other side: xrow_c is
-  // [rows][nc] (a block = whole rows of it) and xcolT_r is [cols][nr].
+  const Wire w = wire_of(c);
+  const size_t m = (size_t)w.m;
+  const int32_t *send_a = w.send, *send_b = w.send + p.off_a[G] * m;
+  // Both kinds of block arrive contiguous on the other side: region a is
+  // [rows][nc] (a block = whole rows of it) and region b is [cols][nr].
+  // Elements travel as 4-byte words whatever they hold.
   NCCL_TRY(c, ncclGroupStart());
   for (int h = 0; h < G; h++) {
-    if ((long long)nr * p.nc[h] > 0) NCCL_TRY(c, ncclSend(send_a + p.off_a[h], (size_t)nr * p.nc[h], ncclInt32, h, c->comm, s));
-    if ((long long)p.nr[h] * nc > 0) NCCL_TRY(c, ncclRecv(c->xrow_c + (long long)p.r0[h] * nc, (size_t)p.nr[h] * nc, ncclInt32, h, c->comm, s));
-    if ((long long)nc * p.nr[h] > 0) NCCL_TRY(c, ncclSend(send_b + p.off_b[h], (size_t)nc * p.nr[h], ncclInt32, h, c->comm, s));
-    if ((long long)p.nc[h] * nr > 0) NCCL_TRY(c, ncclRecv(c->xcolT_r + (long long)p.c0[h] * nr, (size_t)p.nc[h] * nr, ncclInt32, h, c->comm, s));
+    if ((long long)nr * p.nc[h] > 0) NCCL_TRY(c, ncclSend(send_a + p.off_a[h] * m, (size_t)nr * p.nc[h] * m, ncclInt32, h, c->comm, s));
+    if ((long long)p.nr[h] * nc > 0) NCCL_TRY(c, ncclRecv(w.recv_a + (size_t)p.r0[h] * nc * m, (size_t)p.nr[h] * nc * m, ncclInt32, h, c->comm, s));
+    if ((long long)nc * p.nr[h] > 0) NCCL_TRY(c, ncclSend(send_b + p.off_b[h] * m, (size_t)nc * p.nr[h] * m, ncclInt32, h, c->comm, s));
+    if ((long long)p.nc[h] * nr > 0) NCCL_TRY(c, ncclRecv(w.recv_b + (size_t)p.c0[h] * nr * m, (size_t)p.nc[h] * nr * m, ncclInt32, h, c->comm, s));
   }
   NCCL_TRY(c, ncclGroupEnd());
-  return ADMM_OK;
+  return unpack_received(c);
 }
 
 int admm_exchange_counts(admm_ctx *c, int64_t *send_counts, int64_t *recv_counts) {
@@ -770,8 +829,9 @@ int admm_exchange_counts(admm_ctx *c, int64_t *send_counts, int64_t *recv_counts
   if (!is_chain(c)) return fail(c, ADMM_E_STATE, "the label exchange belongs to the chain solver");
   const ExchangePlan p = make_plan(c);
   for (int h = 0; h < c->d.nranks; h++) {
-    if (send_counts) send_counts[h] = (int64_t)c->st.nrows * p.nc[h] + (int64_t)c->st.ncols * p.nr[h];
-    if (recv_counts) recv_counts[h] = (int64_t)p.nr[h] * c->st.ncols + (int64_t)p.nc[h] * c->st.nrows;
+    const int64_t m = c->d.exchange == ADMM_EXCHANGE_DENSE ? c->d.k : 1;
+    if (send_counts) send_counts[h] = m * ((int64_t)c->st.nrows * p.nc[h] + (int64_t)c->st.ncols * p.nr[h]);
+    if (recv_counts) recv_counts[h] = m * ((int64_t)p.nr[h] * c->st.ncols + (int64_t)p.nc[h] * c->st.nrows);
   }
   return ADMM_OK;
 }
@@ -786,13 +846,15 @@ int admm_exchange_pack_host(admm_ctx *c, int32_t *host_send) {
   const ExchangePlan p = make_plan(c);
   if ((rc = pack_labels(c, p))) return rc;
   const int G = c->d.nranks;
-  const int *send_a = c->sendbuf, *send_b = c->sendbuf + p.off_a[G];
+  const Wire w = wire_of(c);
+  const size_t m = (size_t)w.m;
+  const int32_t *send_a = w.send, *send_b = w.send + p.off_a[G] * m;
   int32_t *dst = host_send;
   for (int h = 0; h < G; h++) {  // peer-major: [a_h | b_h]
-    const size_t na = (size_t)c->st.nrows * p.nc[h], nb = (size_t)c->st.ncols * p.nr[h];
-    if (na) HIP_TRY(c, hipMemcpyAsync(dst, send_a + p.off_a[h], na * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    const size_t na = (size_t)c->st.nrows * p.nc[h] * m, nb = (size_t)c->st.ncols * p.nr[h] * m;
+    if (na) HIP_TRY(c, hipMemcpyAsync(dst, send_a + p.off_a[h] * m, na * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     dst += na;
-    if (nb) HIP_TRY(c, hipMemcpyAsync(dst, send_b + p.off_b[h], nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (nb) HIP_TRY(c, hipMemcpyAsync(dst, send_b + p.off_b[h] * m, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     dst += nb;
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -809,13 +871,16 @@ int admm_exchange_unpack_host(admm_ctx *c, const int32_t *host_recv) {
   const ExchangePlan p = make_plan(c);
   const int nr = c->st.nrows, nc = c->st.ncols;
   const int32_t *src = host_recv;
+  const Wire w = wire_of(c);
+  const size_t m = (size_t)w.m;
   for (int h = 0; h < c->d.nranks; h++) {  // from peer h: its rows on my columns, then its columns on my rows
-    const size_t na = (size_t)p.nr[h] * nc, nb = (size_t)p.nc[h] * nr;
-    if (na) HIP_TRY(c, hipMemcpyAsync(c->xrow_c + (long long)p.r0[h] * nc, src, na * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    const size_t na = (size_t)p.nr[h] * nc * m, nb = (size_t)p.nc[h] * nr * m;
+    if (na) HIP_TRY(c, hipMemcpyAsync(w.recv_a + (size_t)p.r0[h] * nc * m, src, na * sizeof(int), hipMemcpyHostToDevice, c->stream));
     src += na;
-    if (nb) HIP_TRY(c, hipMemcpyAsync(c->xcolT_r + (long long)p.c0[h] * nr, src, nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (nb) HIP_TRY(c, hipMemcpyAsync(w.recv_b + (size_t)p.c0[h] * nr * m, src, nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
     src += nb;
   }
+  if ((rc = unpack_received(c))) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller's buffer may be reused at once
   return ADMM_OK;
 }
@@ -826,7 +891,7 @@ int admm_communicate_group(admm_ctx **ctxs, int n) {
     admm_ctx *c = ctxs[g];
     if (!c) return ADMM_E_ARG;
     if (!is_chain(c) || c->d.nranks != n || c->d.rank != g || c->d.rows != ctxs[0]->d.rows ||
-        c->d.cols != ctxs[0]->d.cols || c->d.k != ctxs[0]->d.k)
+        c->d.cols != ctxs[0]->d.cols || c->d.k != ctxs[0]->d.k || c->d.exchange != ctxs[0]->d.exchange)
       return fail(c, ADMM_E_ARG, "admm_communicate_group needs the n strips of one problem, in rank order");
     if (!c->inited) return fail(c, ADMM_E_STATE, "admm_communicate_group before admm_init");
   }
@@ -852,12 +917,15 @@ int admm_communicate_group(admm_ctx **ctxs, int n) {
       admm_ctx *sd = ctxs[g];
       const ExchangePlan &p = plans[g];
       HIP_TRY(r, hipStreamWaitEvent(r->stream, sd->ev_packed, 0));
-      const int *send_a = sd->sendbuf, *send_b = sd->sendbuf + p.off_a[n];
-      const size_t na = (size_t)sd->st.nrows * nc, nb = (size_t)sd->st.ncols * nr;
-      if (na) HIP_TRY(r, hipMemcpyPeerAsync(r->xrow_c + (long long)p.r0[g] * nc, r->d.device, send_a + p.off_a[h], sd->d.device, na * sizeof(int), r->stream));
-      if (nb) HIP_TRY(r, hipMemcpyPeerAsync(r->xcolT_r + (long long)p.c0[g] * nr, r->d.device, send_b + p.off_b[h], sd->d.device, nb * sizeof(int), r->stream));
+      const Wire ws = wire_of(sd), wr = wire_of(r);
+      const size_t m = (size_t)ws.m;
+      const int32_t *send_a = ws.send, *send_b = ws.send + p.off_a[n] * m;
+      const size_t na = (size_t)sd->st.nrows * nc * m, nb = (size_t)sd->st.ncols * nr * m;
+      if (na) HIP_TRY(r, hipMemcpyPeerAsync(wr.recv_a + (size_t)p.r0[g] * nc * m, r->d.device, send_a + p.off_a[h] * m, sd->d.device, na * sizeof(int), r->stream));
+      if (nb) HIP_TRY(r, hipMemcpyPeerAsync(wr.recv_b + (size_t)p.c0[g] * nr * m, r->d.device, send_b + p.off_b[h] * m, sd->d.device, nb * sizeof(int), r->stream));
     }
     HIP_TRY(r, hipEventRecord(r->ev_pulled, r->stream));
+    if ((rc = unpack_received(r))) return rc;
   }
   // 3. a strip's send buffer is free again once everybody has pulled from it
   for (int g = 0; g < n; g++) {

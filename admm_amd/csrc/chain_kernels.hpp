@@ -921,4 +921,28 @@ __global__ void label_block_copy_kernel(int *__restrict__ dst, long long dst_ld,
   }
 }
 
+// Dense form of the strip exchange: the marginals of the chains' own
+// solutions as float k-vectors (one-hot of the label; 1/k everywhere before
+// the first solve), which is what the reference moves between ranks
+// (Grid.cpp:1646-1656 sends rows of vertMuArr).
+__global__ void labels_to_marginals_kernel(float *__restrict__ mu, const int *__restrict__ lab,
+                                           long long n, int k, float inv_k) {
+  const long long total = n * k;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x)
+    mu[i] = chain_mu(lab[i / k], (int)(i % k), inv_k);
+}
+
+// The inverse: the label whose marginal is 1, or -1 for the uniform vector.
+__global__ void marginals_to_labels_kernel(int *__restrict__ lab, const float *__restrict__ mu,
+                                           long long n, int k) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float *v = mu + i * k;
+    int x = -1;
+    for (int l = k - 1; l >= 0; l--) x = (v[l] == 1.0f) ? l : x;
+    lab[i] = x;
+  }
+}
+
 }  // namespace admm

@@ -43,7 +43,9 @@ extern "C" {
 
 /* What crosses GPUs between the row and the column chains (chain solver). */
 #define ADMM_EXCHANGE_LABELS 0 /* int32 labels; consensus rebuilt on both sides */
-#define ADMM_EXCHANGE_DENSE 1  /* one-hot marginals as float k-vectors          */
+#define ADMM_EXCHANGE_DENSE 1  /* the marginals as float k-vectors, the form the
+                                * reference sends (Grid.cpp:1646-1656); k times
+                                * the bytes, bit-identical results             */
 
 typedef struct admm_ctx admm_ctx;
 
@@ -96,7 +98,8 @@ int admm_init(admm_ctx *ctx);
  * subproblem of every tree (Tree.cpp:64-274). */
 int admm_compute(admm_ctx *ctx);
 /* Grid::Communicate (Grid.cpp:1509-1526, 1639-1663).  One strip: nothing to
- * exchange.  Several strips: RCCL all-to-all of the chain labels. */
+ * exchange.  Several strips: RCCL all-to-all (grouped send / receive) of the
+ * chain labels, or of their marginals with ADMM_EXCHANGE_DENSE. */
 int admm_communicate(admm_ctx *ctx);
 /* The same exchange when all n strips of a problem live in this process (one
  * context per strip, rank order, on one GPU or on several): device-to-device
@@ -107,8 +110,9 @@ int admm_communicate(admm_ctx *ctx);
 int admm_communicate_group(admm_ctx **ctxs, int n);
 /* The same exchange staged through host memory, for a caller that brings its
  * own transport (the reference's is MPI_Isend / MPI_Irecv on packed host
- * buffers, Grid.cpp:1648-1662).  admm_exchange_counts gives the labels sent to
- * and received from every rank; admm_exchange_pack_host fills host_send,
+ * buffers, Grid.cpp:1648-1662).  admm_exchange_counts gives the 4-byte
+ * elements (labels; k floats per label with ADMM_EXCHANGE_DENSE) sent to and
+ * received from every rank; admm_exchange_pack_host fills host_send,
  * peer-major, and waits for it; the caller moves block h of every rank to
  * rank h; admm_exchange_unpack_host takes the received blocks, peer-major. */
 int admm_exchange_counts(admm_ctx *ctx, int64_t *send_counts, int64_t *recv_counts);

@@ -19,15 +19,16 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, R, C, k, iters, pw, out_dir):
+def _worker(rank, world, port, R, C, k, iters, pw, exchange, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    import admm_amd as A  # the HIP library before torch: one HIP runtime in the process
+    import admm_amd as A  # binds its HIP runtime locally, so torch (gloo only here) can be loaded beside it
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle as O
     un, W = O.synth_problem(R, C, k, 1234, pw)
     g = A.Grid(rank=rank, nprocs=world, device=0)
+    g.exchange = exchange
     g.SetPartitioner(A.ROW)
     g.SetPenalties(0.5, 1.0)
     g.SetGlobalInfo(R, C, k)
@@ -48,13 +49,24 @@ def _worker(rank, world, port, R, C, k, iters, pw, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,R,C,k,pw", [(2, 40, 70, 32, "potts"), (3, 33, 20, 8, "dense")])
-def test_two_processes_one_strip_each(tmp_path, world, R, C, k, pw):
-    import torch.multiprocessing as mp
+@pytest.mark.parametrize("world,R,C,k,pw,exchange", [(2, 40, 70, 32, "potts", 0), (3, 33, 20, 8, "dense", 0),
+                                                     (2, 21, 34, 16, "trunc_linear", 1)])
+def test_two_processes_one_strip_each(tmp_path, world, R, C, k, pw, exchange):
+    import multiprocessing as mp  # torch stays out of this process: the workers load it after the HIP library
     from oracle import oracle as O
     iters = 6
-    mp.get_context("spawn")
-    mp.spawn(_worker, args=(world, _free_port(), R, C, k, iters, pw, str(tmp_path)), nprocs=world, join=True)
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, R, C, k, iters, pw, exchange, str(tmp_path)))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0, "worker exit code %r" % (p.exitcode,)
     un, W = O.synth_problem(R, C, k, 1234, pw)
     o = O.ChainOracle(R, C, k, un, W)
     o.init()

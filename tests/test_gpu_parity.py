@@ -15,9 +15,10 @@ OBJ_RTOL = 1e-9      # binary64 sums in a different order
 EDGE_RTOL = 1e-5     # double exp/log of the device library vs glibc, rounded to float
 
 
-def _chain_grid(R, C, k, un, W, batch=1, rank=0, nprocs=1):
+def _chain_grid(R, C, k, un, W, batch=1, rank=0, nprocs=1, exchange=0):
     import admm_amd as A
     g = A.Grid(rank=rank, nprocs=nprocs)
+    g.exchange = exchange
     g.SetPartitioner(A.ROW)
     g.SetPenalties(0.5, 1.0)
     g.SetGlobalInfo(R, C, k, batch=batch)
@@ -159,16 +160,19 @@ def test_chain_batch_of_independent_grids():
     g.close()
 
 
+@pytest.mark.parametrize("exchange", [0, 1], ids=["labels", "dense"])
 @pytest.mark.parametrize("G,R,C,k,pw", [(2, 20, 24, 8, "potts"), (3, 17, 10, 32, "dense"), (4, 9, 70, 4, "potts"),
-                                        (8, 64, 64, 16, "trunc_linear"), (5, 3, 7, 5, "dense")])
-def test_chain_strips_equal_single_strip(G, R, C, k, pw):
+                                        (8, 64, 64, 16, "trunc_linear"), (5, 3, 7, 5, "dense"), (2, 6, 5, 2, "potts")])
+def test_chain_strips_equal_single_strip(G, R, C, k, pw, exchange):
     """The grid cut into G row / column strips (all in this process, on one GPU) gives the
-    single-strip result bit for bit; strips may be empty when G exceeds rows or columns."""
+    single-strip result bit for bit; strips may be empty when G exceeds rows or columns.
+    Both wire formats: labels, and the float k-vectors of the marginals."""
     from oracle import oracle as O
     import admm_amd as A
     un, W = O.synth_problem(R, C, k, 1234, pw)
     o = O.ChainOracle(R, C, k, un, W); o.init()
-    grids = [_chain_grid(R, C, k, un, W, rank=r, nprocs=G) for r in range(G)]
+    grids = [_chain_grid(R, C, k, un, W, rank=r, nprocs=G, exchange=exchange) for r in range(G)]
+    A.communicate_group(grids)  # before the first solve: nothing to tell, must change nothing
     for it in range(6):
         o.compute(); o.update()
         for g in grids:
