@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 
 void Grid::check(int rc, const char *what) const {
   if (rc == ADMM_OK) return;
@@ -25,16 +26,95 @@ void Grid::SetGlobalInfo(int rows, int cols, int vps, int eps) {
   numGlobalEdges = rows * (cols - 1) + cols * (rows - 1);
 }
 
+static void gf_check(int rc, const char *what) {
+  if (rc != ADMM_GF_OK) throw AdmmError(ADMM_E_ARG, std::string(what) + ": " + admm_graphfile_last_error());
+}
+
 void Grid::SetGlobalInfo(const std::string &fname) {
-  throw AdmmError(ADMM_E_ARG, "reading '" + fname + "': the CDF-5 reader is not built yet; use SetGlobalInfo(rows, cols, k, k*k) and Generate");
+  admm_graphfile_info info;
+  gf_check(admm_graphfile_read_info(fname.c_str(), &info), "SetGlobalInfo");
+  numGlobalRows = info.rows;
+  numGlobalCols = info.cols;
+  numVertPotentials = info.k;
+  numEdgePotentials = info.k2;
+  numGlobalVerts = (int)info.num_vertices;  // Grid.cpp:680-681: from the file, not rows * cols
+  numGlobalEdges = (int)info.num_edges;
 }
 
 void Grid::Load(const std::string &fname) {
-  throw AdmmError(ADMM_E_ARG, "reading '" + fname + "': the CDF-5 reader is not built yet; use Generate or SetPotentials");
+  if (numVertPotentials <= 0) SetGlobalInfo(fname);
+  const int k = numVertPotentials;
+  if (numEdgePotentials != k * k) throw AdmmError(ADMM_E_ARG, "numEdgePotentials must be numVertPotentials squared");
+  edgeList.assign((size_t)2 * numGlobalEdges, 0);
+  gf_check(admm_graphfile_read_edges(fname.c_str(), 0, numGlobalEdges, edgeList.data()), "Load");
+  vertPotentials.assign((size_t)numGlobalVerts * k, 0.0f);
+  gf_check(admm_graphfile_read_unaries(fname.c_str(), 0, numGlobalVerts, vertPotentials.data(), 1), "Load");
+  if (part == EDGE) {
+    edgePotentials.assign((size_t)numGlobalEdges * k * k, 0.0f);
+    gf_check(admm_graphfile_read_pairwise(fname.c_str(), 0, numGlobalEdges, edgePotentials.data(), 1), "Load");
+    sharedTable = false;
+  } else {
+    // chains: the grid's own edge list, one table for all edges
+    if (numGlobalRows < 1 || numGlobalCols < 1 || (long long)numGlobalRows * numGlobalCols != numGlobalVerts)
+      throw AdmmError(ADMM_E_ARG, "'" + fname + "' does not describe a rows x cols grid; use the EDGE partitioner");
+    std::vector<int> want((size_t)2 * std::max(1, numGlobalRows * (numGlobalCols - 1) + numGlobalCols * (numGlobalRows - 1)));
+    const int E = admm_grid_edges(numGlobalRows, numGlobalCols, want.data());
+    want.resize((size_t)2 * E);
+    if (E != numGlobalEdges || want != edgeList)
+      throw AdmmError(ADMM_E_ARG, "the edge list of '" + fname + "' is not the grid's (Grid::Generate order); use the EDGE partitioner");
+    edgePotentials.assign((size_t)k * k, 0.0f);
+    int shared = 0;
+    gf_check(admm_graphfile_shared_table(fname.c_str(), edgePotentials.data(), 1, &shared), "Load");
+    if (!shared) throw AdmmError(ADMM_E_ARG, "the edges of '" + fname + "' carry different pairwise tables; the chain solver needs one shared table");
+    sharedTable = true;
+  }
+  batch = 1;
+  fromFile = true;
 }
 
 void Grid::Save(const std::string &fname) {
-  throw AdmmError(ADMM_E_ARG, "writing '" + fname + "': the CDF-5 writer is not built yet");
+  if (vertPotentials.empty()) throw AdmmError(ADMM_E_STATE, "Generate, Load or Convert before Save");
+  if (batch != 1) throw AdmmError(ADMM_E_ARG, "a graph file holds one graph (batch == 1)");
+  const int k = numVertPotentials;
+  std::vector<int> el = edgeList;
+  if (el.empty()) {
+    el.resize((size_t)2 * std::max(1, numGlobalEdges));
+    el.resize((size_t)2 * admm_grid_edges(numGlobalRows, numGlobalCols, el.data()));
+  }
+  // the file holds scores: the negated costs (Grid.cpp:547-560 undone)
+  std::vector<float> un(vertPotentials.size()), pw(edgePotentials.size());
+  for (size_t i = 0; i < un.size(); i++) un[i] = -vertPotentials[i];
+  for (size_t i = 0; i < pw.size(); i++) pw[i] = -edgePotentials[i];
+  admm_graphfile_info info;
+  info.version = 0;
+  info.rows = numGlobalRows;
+  info.cols = numGlobalCols;
+  info.num_vertices = numGlobalVerts;
+  info.num_edges = numGlobalEdges;
+  info.k = k;
+  info.k2 = k * k;
+  gf_check(admm_graphfile_write(fname.c_str(), &info, el.data(), un.data(), pw.data(), sharedTable ? 0 : 1), "Save");
+}
+
+void Grid::Convert(const std::string &manifest) {
+  // through a temporary graph file: the converter of the library is the one implementation
+  const std::string tmp = manifest + ".converted.nc";
+  gf_check(admm_graphfile_convert(manifest.c_str(), tmp.c_str()), "Convert");
+  const Partitioner keep = part;
+  part = EDGE;
+  numVertPotentials = 0;
+  try {
+    Load(tmp);
+  } catch (...) {
+    part = keep;
+    remove(tmp.c_str());
+    throw;
+  }
+  part = keep;
+  remove(tmp.c_str());
+  // The raw files hold what a graph file holds (scores): this object now has
+  // their negation, as after any Load, and Save negates back, so that
+  // Convert + Save writes the raw values unchanged (Grid.cpp:1032-1044, 1110-1126).
 }
 
 void Grid::SetPartitioner(Partitioner aPart) {
@@ -69,6 +149,8 @@ void Grid::Generate(unsigned seed, const std::string &pairwise) {
     }
   if (pairwise == "dense") admm_lcg_fill(first_state, (int64_t)k * k, edgePotentials.data());
   sharedTable = true;
+  fromFile = false;
+  edgeList.clear();
 }
 
 void Grid::SetPotentials(const std::vector<float> &unary, const std::vector<float> &pairwise, bool perEdge) {
@@ -86,6 +168,13 @@ void Grid::InitOptimization() {
   d.penalty = penalty; d.penalty_prime = penaltyPrime; d.rho = rhoEdge;
   d.device = device; d.rank = part == EDGE ? 0 : rank; d.nranks = part == EDGE ? 1 : numProcs;
   d.exchange = ADMM_EXCHANGE_LABELS;
+  if (part == EDGE && fromFile) {  // any graph: hand the file's edge list over (Grid.cpp:476-494)
+    d.edge_list = edgeList.data();
+    d.num_vertices = numGlobalVerts;
+    d.num_edges = numGlobalEdges;
+    if (d.rows < 1) d.rows = 1;
+    if (d.cols < 1) d.cols = 1;
+  }
   if (ctx) { admm_destroy(ctx); ctx = nullptr; }
   const int rc = admm_create(&d, &ctx);
   if (rc != ADMM_OK) throw AdmmError(rc, std::string("admm_create: ") + admm_last_error(nullptr));

@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 
+#include "../../../include/admm_graphfile.h"
 #include "../../../include/admm_hip.h"
 #include "BBox.h"
 #include "GraphBase.h"
@@ -29,6 +30,8 @@ class Grid : public GraphBase {
   Partitioner part = EDGE;
   int rank = 0, numProcs = 1, device = 0;
   bool sharedTable = true;  // edgePotentials holds one k*k table, not one per edge
+  std::vector<int> edgeList;  // 2 * numGlobalEdges vertex ids when the graph came from a file
+  bool fromFile = false;
   admm_ctx *ctx = nullptr;
 
   void check(int rc, const char *what) const;
@@ -43,7 +46,8 @@ class Grid : public GraphBase {
 
   void SetPenalties(float p, float pp) { penalty = p; penaltyPrime = pp; }
   void SetGlobalInfo(int globalRowSize, int globalColSize, int verticePotentialSize, int edgePotentialSize);
-  void SetGlobalInfo(const std::string &fname);  // file input: not built yet
+  // Sizes from a graph file's attributes (Grid.cpp:654-702).
+  void SetGlobalInfo(const std::string &fname);
   void SetBatch(int n) { batch = n; }
   void SetPartitioner(Partitioner aPart);
   void SetRhoEdge(float aRhoEdge) { rhoEdge = aRhoEdge; }
@@ -54,8 +58,17 @@ class Grid : public GraphBase {
   // reference draws from rand() (Grid.cpp:631-645).
   void Generate(unsigned seed, const std::string &pairwise);
   void Generate() override { Generate(1234u, "potts"); }
-  void Load(const std::string &fname);           // file input: not built yet
-  void Save(const std::string &fname) override;  // file output: not built yet
+  // Graph file -> edge list and potentials, sign-flipped into costs as the
+  // reference's loader does (Grid.cpp:445-565).  EDGE: any graph.  ROW: the
+  // file must hold a rows x cols grid in Generate's edge order with one
+  // pairwise table common to all edges.
+  void Load(const std::string &fname);
+  // Potentials held by this object -> graph file, sign-flipped back into the
+  // scores a file holds (Grid.cpp:1049-1131).
+  void Save(const std::string &fname) override;
+  // Raw binary files named by a manifest -> this object (Grid.cpp:985-1045);
+  // follow with Save, as Converter.cpp does.
+  void Convert(const std::string &manifest);
   // Potentials as the reference holds them after its loader's sign flip.
   void SetPotentials(const std::vector<float> &unary, const std::vector<float> &pairwise, bool perEdge);
 

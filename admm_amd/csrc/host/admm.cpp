@@ -1,11 +1,15 @@
 // Driver with the reference's loop (admm.cpp:41-125): set the partitioner and
 // the penalties, describe the problem, initialise, then per iteration Compute,
 // Communicate, Update and the objective, and print the same timing labels.
-// Input is synthetic (the reference reads a PnetCDF file named by argv[1]).
+// Input is a graph file named by argv[1], as in the reference (admm.cpp:30),
+// or a synthetic grid.
 //
+//   admm <graph file> [--solver edge|chain] [--iters N] [--strips G] [--quiet]
 //   admm <rows> <cols> <k> [--solver edge|chain] [--iters N] [--pairwise potts|trunc_linear|dense]
-//        [--seed S] [--strips G] [--batch B] [--quiet]
+//        [--seed S] [--strips G] [--batch B] [--quiet] [--save FILE]
 //
+// --save FILE writes the synthetic problem as a graph file (the reference's
+// GENERATE build, admm.cpp:32-39) before solving it.
 // --strips G cuts the grid into G row/column strips held by this one process,
 // strip g on device g modulo the device count.
 #include <chrono>
@@ -25,16 +29,20 @@ static double now() {
 }
 
 int main(int argc, char *argv[]) {
-  if (argc < 4) {
-    fprintf(stderr, "usage: %s <rows> <cols> <k> [--solver edge|chain] [--iters N] [--pairwise KIND] [--seed S] [--strips G] [--batch B] [--quiet]\n", argv[0]);
+  const bool fromFile = argc >= 2 && (argv[1][0] < '0' || argv[1][0] > '9');
+  if (argc < 2 || (!fromFile && argc < 4)) {
+    fprintf(stderr, "usage: %s <graph file> [--solver edge|chain] [--iters N] [--strips G] [--quiet]\n"
+                    "       %s <rows> <cols> <k> [--solver edge|chain] [--iters N] [--pairwise KIND] [--seed S] [--strips G] [--batch B] [--quiet] [--save FILE]\n",
+            argv[0], argv[0]);
     return 2;
   }
-  const int rows = atoi(argv[1]), cols = atoi(argv[2]), k = atoi(argv[3]);
-  std::string solver = "edge", pairwise = "potts";
+  const std::string fname = fromFile ? argv[1] : "";
+  const int rows = fromFile ? 0 : atoi(argv[1]), cols = fromFile ? 0 : atoi(argv[2]), k = fromFile ? 0 : atoi(argv[3]);
+  std::string solver = "edge", pairwise = "potts", saveTo;
   int totalRuns = 500, strips = 1, batch = 1;  // admm.cpp:74
   unsigned seed = 1234;
   bool quiet = false;
-  for (int i = 4; i < argc; i++) {
+  for (int i = fromFile ? 2 : 4; i < argc; i++) {
     auto val = [&](const char *n) -> const char * {
       if (i + 1 >= argc) { fprintf(stderr, "%s needs a value\n", n); exit(2); }
       return argv[++i];
@@ -45,6 +53,7 @@ int main(int argc, char *argv[]) {
     else if (!strcmp(argv[i], "--seed")) seed = (unsigned)strtoul(val("--seed"), nullptr, 10);
     else if (!strcmp(argv[i], "--strips")) strips = atoi(val("--strips"));
     else if (!strcmp(argv[i], "--batch")) batch = atoi(val("--batch"));
+    else if (!strcmp(argv[i], "--save")) saveTo = val("--save");
     else if (!strcmp(argv[i], "--quiet")) quiet = true;
     else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
   }
@@ -60,12 +69,17 @@ int main(int argc, char *argv[]) {
       Grid &grid = *grids.back();
       grid.SetPartitioner(solver == "edge" ? EDGE : ROW);  // admm.cpp:41
       grid.SetPenalties(0.5, 1.0);                          // admm.cpp:44
-      grid.SetGlobalInfo(rows, cols, k, k * k);
+      if (fromFile) grid.SetGlobalInfo(fname);               // admm.cpp:66
+      else grid.SetGlobalInfo(rows, cols, k, k * k);
       grid.SetBatch(batch);
       ptrs.push_back(&grid);
     }
     const double allocTime = now() - t; t = now();
-    for (auto &g : grids) g->Generate(seed, pairwise);
+    for (auto &g : grids) {
+      if (fromFile) g->Load(fname);                          // admm.cpp:70
+      else g->Generate(seed, pairwise);
+    }
+    if (!saveTo.empty()) grids[0]->Save(saveTo);
     const double loadTime = now() - t; t = now();
     for (auto &g : grids) g->InitOptimization();
     const double initTime = now() - t; t = now();

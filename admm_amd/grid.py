@@ -7,10 +7,11 @@ FinalizeOptimization.  Every method forwards to the C ABI of libadmm_hip.so;
 nothing is computed in Python.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
-from . import _lib
+from . import _lib, graphfile
 from ._lib import (AdmmDesc, AdmmError, EXCHANGE_DENSE, EXCHANGE_LABELS,
                    SOLVER_CHAIN_MINSUM, SOLVER_EDGE_BETHE, lib)
 
@@ -97,7 +98,16 @@ class Grid:
     def SetRhoEdge(self, rho):
         self.rhoEdge = float(rho)
 
-    def SetGlobalInfo(self, rows, cols, vert_potential_size, edge_potential_size=None, batch=1):
+    def SetGlobalInfo(self, rows, cols=None, vert_potential_size=None, edge_potential_size=None, batch=1):
+        """SetGlobalInfo(rows, cols, k, k*k) (Grid.cpp:96-116), or
+        SetGlobalInfo(fname): the sizes a graph file states (Grid.cpp:654-702)."""
+        if isinstance(rows, (str, os.PathLike)):
+            info = graphfile.read_info(rows)
+            self.rows, self.cols, self.k, self.batch = info.rows, info.cols, info.k, 1
+            self._file_info = info
+            if info.k2 != info.k ** 2:
+                raise ValueError("numEdgePotentials must be numVertPotentials squared")
+            return
         if edge_potential_size is not None and edge_potential_size != vert_potential_size ** 2:
             raise ValueError("numEdgePotentials must be numVertPotentials squared")
         self.rows, self.cols, self.k, self.batch = int(rows), int(cols), int(vert_potential_size), int(batch)
@@ -108,13 +118,56 @@ class Grid:
         self._num_vertices = int(num_vertices)
 
     # ---- data ----
-    def Load(self, unary, pairwise, per_edge=False):
-        """Potentials as Grid holds them after the loader's sign flip
-        (Grid.cpp:547-560): costs.  unary [batch*rows*cols, k]; pairwise either
-        one k x k table or [E, k*k]."""
+    def Load(self, unary, pairwise=None, per_edge=False):
+        """Load(fname): a graph file (Grid.cpp:445-565), sign-flipped into costs
+        as the reference's loader does.  EDGE partitioner: any graph, one table
+        per edge.  ROW: the file must hold a rows x cols grid in Generate's edge
+        order whose edges all carry the same table.
+        Load(unary, pairwise, per_edge): potentials as Grid holds them after
+        the sign flip (Grid.cpp:547-560), i.e. costs.  unary [batch*rows*cols, k];
+        pairwise either one k x k table or [E, k*k]."""
+        if isinstance(unary, (str, os.PathLike)):
+            return self._load_file(unary)
         self._unary = np.ascontiguousarray(unary, dtype=np.float32).reshape(-1)
         self._pairwise = np.ascontiguousarray(pairwise, dtype=np.float32).reshape(-1)
         self._per_edge = bool(per_edge)
+
+    def _load_file(self, fname):
+        info = graphfile.read_info(fname)
+        if self.k == 0:
+            self.SetGlobalInfo(fname)
+        if (info.k, info.rows, info.cols) != (self.k, self.rows, self.cols):
+            raise ValueError("SetGlobalInfo disagrees with %s" % (fname,))
+        el = graphfile.read_edges(fname).reshape(-1)
+        un = graphfile.read_unaries(fname, negate=True)
+        if self.part == EDGE:
+            self.SetGraph(info.num_vertices, el)
+            self.Load(un, graphfile.read_pairwise(fname, negate=True), per_edge=True)
+            return
+        if info.rows < 1 or info.cols < 1 or info.rows * info.cols != info.num_vertices:
+            raise ValueError("%s does not describe a rows x cols grid; use the EDGE partitioner" % (fname,))
+        if not np.array_equal(el, grid_edges(info.rows, info.cols)):
+            raise ValueError("the edge list of %s is not the grid's (Grid::Generate order); use the EDGE partitioner" % (fname,))
+        table, shared = graphfile.shared_table(fname, negate=True)
+        if not shared:
+            raise ValueError("the edges of %s carry different pairwise tables; the chain solver needs one shared table" % (fname,))
+        self._edge_list = None
+        self.Load(un, table)
+
+    def Save(self, fname, version=0):
+        """Grid::Save (Grid.cpp:1049-1131): the potentials this object holds,
+        sign-flipped back into the scores a graph file holds."""
+        if self._unary is None:
+            raise AdmmError(-2, "Load or Generate before Save")
+        if self.batch != 1:
+            raise ValueError("a graph file holds one graph (batch == 1)")
+        if self._edge_list is not None:
+            el, V = self._edge_list, self._num_vertices
+        else:
+            el, V = grid_edges(self.rows, self.cols), self.rows * self.cols
+        pw = -self._pairwise
+        graphfile.write(fname, V, el, -self._unary, pw.reshape(-1, self.k * self.k) if self._per_edge else pw.reshape(self.k, self.k),
+                        rows=self.rows, cols=self.cols, version=version)
 
     def Generate(self, seed=1234, pairwise="potts"):
         """Synthetic potentials: LCG unaries in [0,1) drawn node-major, grid g
