@@ -65,6 +65,7 @@ struct admm_ctx {
   int *xo_c = nullptr;     // [batch][ncols][rows]   = xrow_c transposed: what the column sweep reads
   uint8_t *bp_r = nullptr, *bp_c = nullptr;
   float *d_W = nullptr, *d_Wsplit = nullptr, *d_Wt = nullptr;
+  float *d_WsplitT = nullptr, *d_WtT = nullptr;  // transposes, for the half chains swept backwards
   float *d_chain_min = nullptr;
   // The linear objective of a solve has two per-chain terms: the pairwise one
   // is written by that solve's sweep, the unary one by the NEXT sweep (which
@@ -149,6 +150,7 @@ struct SweepShape {
 // (NS > 1) so that a wavefront's 64 lanes are all busy on one chain; when
 // chains are plentiful, narrow labels pack several chains into a wavefront.
 SweepShape pick_shape(int KP, long long nchains) {
+  nchains *= 2;  // every chain is swept as two half chains, one wavefront slot each
   const long long simd_slots = 256LL * 4 * 2;  // two wavefronts per SIMD
   int NS = std::min(64 / KP, KP);
   if (KP <= 16) {
@@ -184,11 +186,11 @@ int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
   int w = 0;
   for (int i = 0; i < a.nseg; i++) {
     a.wave_begin[i] = w;
-    w += (a.seg[i].nchains + CPW - 1) / CPW;
+    w += 2 * ((a.seg[i].nchains + CPW - 1) / CPW);  // left and right half of every group of chains
   }
   a.wave_begin[a.nseg] = w;
   if (w == 0) return ADMM_OK;
-  const int blocks = (w + 3) / 4;
+  const int blocks = (w + kChainBlock / 64 - 1) / (kChainBlock / 64);
   hipStream_t s = c->stream;
 #define SWEEP_CASE(kp, ns) \
   if (sh.KP == kp && sh.NS == ns) { launch_sweep_t<kp, ns, DUAL>(a, blocks, s); goto launched; }
@@ -223,8 +225,8 @@ void fill_seg_cols(const admm_ctx *c, ChainSeg &s, bool dual) {
   const admm_desc &d = c->d;
   s.theta = c->th_c; s.lam = c->lam_c; s.x = c->xcolT_c; s.xo = c->xo_c; s.bp = c->bp_c;
   s.chain_min = dual ? c->d_chain_min + (long long)d.batch * c->st.nrows : nullptr;
-  s.chain_lin = c->d_chain_lin + (long long)d.batch * c->st.nrows;
-  s.chain_unary = c->d_chain_unary + (long long)d.batch * c->st.nrows;
+  s.chain_lin = c->d_chain_lin + 2LL * d.batch * c->st.nrows;
+  s.chain_unary = c->d_chain_unary + 2LL * d.batch * c->st.nrows;
   s.nchains = d.batch * c->st.ncols;
   s.T = d.rows;
   s.cpg = std::max(1, c->st.ncols);
@@ -244,10 +246,12 @@ int chain_sweep(admm_ctx *c, bool dual) {
   a.inv_k = c->inv_k;
   a.Wt = dual ? c->d_Wsplit : c->d_Wt;
   a.Wsplit = c->d_Wsplit;
+  a.WtT = dual ? c->d_WsplitT : c->d_WtT;
+  a.WsplitT = c->d_WsplitT;
   SweepShape sh = pick_shape(c->KP, (long long)a.seg[0].nchains + a.seg[1].nchains);
   if (!dual && getenv("ADMM_SWEEP_STAMPS")) {
     // diagnostic: per-wavefront clock stamps (start, end of forward pass, end), summarised on stderr
-    const size_t nw = (size_t)a.seg[0].nchains + a.seg[1].nchains + 8;
+    const size_t nw = 2 * ((size_t)a.seg[0].nchains + a.seg[1].nchains) + 16;
     unsigned long long *d_st = nullptr;
     HIP_TRY(c, hipMalloc((void **)&d_st, nw * 3 * sizeof(unsigned long long)));
     HIP_TRY(c, hipMemset(d_st, 0, nw * 3 * sizeof(unsigned long long)));
@@ -414,9 +418,13 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
     return fail(nullptr, ADMM_E_ARG, "more than 2^31-1 vertices");
   if (d.solver == ADMM_SOLVER_CHAIN_MINSUM) {
     if (graph) return fail(nullptr, ADMM_E_ARG, "the chain solver needs a grid, not an edge list");
-    // the sweep addresses a chain's operands with 32-bit element offsets
-    if (((long long)d.rows + 64) * d.cols * d.k >= (1LL << 31))
-      return fail(nullptr, ADMM_E_ARG, "(rows + 64) * cols * k must stay below 2^31 per grid");
+    // the sweep reaches a half chain's operands through a buffer descriptor:
+    // the bytes one wavefront spans (half a chain plus prefetch overrun, and
+    // the distance between the chains that share a wavefront) must stay below 4 GiB
+    const long long span_col = (((long long)d.rows + 1) / 2 + 130) * d.cols * d.k + 64LL * d.k;
+    const long long span_row = (((long long)d.cols + 1) / 2 + 130) * d.k + 64LL * d.cols * d.k;
+    if (span_col >= (1LL << 30) || span_row >= (1LL << 30))
+      return fail(nullptr, ADMM_E_ARG, "grid too large for the sweep's 32-bit offsets: (rows / 2 + 130) * cols * k must stay below 2^30");
     if (d.nranks > 1 && d.batch != 1) return fail(nullptr, ADMM_E_ARG, "strips (nranks > 1) need batch == 1; shard a batch by grids instead");
     if (d.exchange != ADMM_EXCHANGE_LABELS && d.exchange != ADMM_EXCHANGE_DENSE)
       return fail(nullptr, ADMM_E_ARG, "unknown exchange mode %d", d.exchange);
@@ -480,33 +488,39 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
     const size_t k = d.k, B = d.batch;
     const size_t nrow_nodes = B * (size_t)c->st.nrows * d.cols;
     const size_t ncol_nodes = B * (size_t)d.rows * c->st.ncols;
-    const size_t Tp_r = ((size_t)d.cols + kChunk - 1) / kChunk * kChunk;
-    const size_t Tp_c = ((size_t)d.rows + kChunk - 1) / kChunk * kChunk;
+    // back-pointer scratch: two half chains per chain, each padded to whole 64-step chunks
+    const size_t Tp_r = 2 * ((((size_t)d.cols + 1) / 2 + kChunk - 1) / kChunk * kChunk);
+    const size_t Tp_c = 2 * ((((size_t)d.rows + 1) / 2 + kChunk - 1) / kChunk * kChunk);
     // The sweep prefetches operands up to one unrolled block (<= 64 steps)
-    // past a chain's end without predication; the slack keeps those reads
-    // inside the allocation.  A column chain's step is one strip row.
+    // past a half chain's end without predication, forwards for a left half
+    // and backwards for a right half; slack on both sides of every operand
+    // array keeps those reads inside the allocation.  A column chain's step is
+    // one strip row.
     const size_t slack_r = 64 * (size_t)std::max(d.cols, 1) * k;
     const size_t slack_c = 64 * (size_t)std::max(d.nranks == 1 ? d.cols : c->st.ncols, 1) * k;
     const size_t slack = std::max(slack_r, slack_c);
-    if ((rc = dev_alloc(c, &c->th_r, nrow_nodes * k + slack)) || (rc = dev_alloc(c, &c->lam_r, nrow_nodes * k + slack)) ||
-        (rc = dev_alloc(c, &c->lam_c, ncol_nodes * k + slack)) ||
+    if ((rc = dev_alloc(c, &c->th_r, nrow_nodes * k + 2 * slack)) || (rc = dev_alloc(c, &c->lam_r, nrow_nodes * k + 2 * slack)) ||
+        (rc = dev_alloc(c, &c->lam_c, ncol_nodes * k + 2 * slack)) ||
         (rc = dev_alloc(c, &c->xrow_r, nrow_nodes)) || (rc = dev_alloc(c, &c->xcolT_c, ncol_nodes)) ||
         (rc = dev_alloc(c, &c->xo_r, nrow_nodes)) || (rc = dev_alloc(c, &c->xo_c, ncol_nodes)) ||
         (rc = dev_alloc(c, &c->bp_r, B * c->st.nrows * Tp_r * c->KP + 16)) ||
         (rc = dev_alloc(c, &c->bp_c, B * c->st.ncols * Tp_c * c->KP + 16)) ||
         (rc = dev_alloc(c, &c->d_W, k * k)) || (rc = dev_alloc(c, &c->d_Wsplit, k * k)) ||
-        (rc = dev_alloc(c, &c->d_Wt, k * k)) ||
+        (rc = dev_alloc(c, &c->d_Wt, k * k)) || (rc = dev_alloc(c, &c->d_WsplitT, k * k)) ||
+        (rc = dev_alloc(c, &c->d_WtT, k * k)) ||
         (rc = dev_alloc(c, &c->d_chain_min, B * ((size_t)c->st.nrows + c->st.ncols))) ||
-        (rc = dev_alloc(c, &c->d_chain_lin, B * ((size_t)c->st.nrows + c->st.ncols))) ||
-        (rc = dev_alloc(c, &c->d_chain_unary, B * ((size_t)c->st.nrows + c->st.ncols))))
+        (rc = dev_alloc(c, &c->d_chain_lin, 2 * B * ((size_t)c->st.nrows + c->st.ncols))) ||
+        (rc = dev_alloc(c, &c->d_chain_unary, 2 * B * ((size_t)c->st.nrows + c->st.ncols))))
       return bail(rc);
-    HIP_TRY_BAIL(hipMemset(c->th_r + nrow_nodes * k, 0, sizeof(float) * slack));
-    HIP_TRY_BAIL(hipMemset(c->lam_r + nrow_nodes * k, 0, sizeof(float) * slack));
-    HIP_TRY_BAIL(hipMemset(c->lam_c + ncol_nodes * k, 0, sizeof(float) * slack));
+    // [slack | data | slack]: the pointers the rest of the code sees are the data's
+    HIP_TRY_BAIL(hipMemset(c->th_r, 0, sizeof(float) * (nrow_nodes * k + 2 * slack)));
+    HIP_TRY_BAIL(hipMemset(c->lam_r, 0, sizeof(float) * (nrow_nodes * k + 2 * slack)));
+    HIP_TRY_BAIL(hipMemset(c->lam_c, 0, sizeof(float) * (ncol_nodes * k + 2 * slack)));
+    c->th_r += slack; c->lam_r += slack; c->lam_c += slack;
     if (d.nranks == 1) {
       c->th_c = c->th_r; c->xrow_c = c->xrow_r; c->xcolT_r = c->xcolT_c;
     } else {
-      if ((rc = dev_alloc(c, &c->th_c, ncol_nodes * k + slack)) ||
+      if ((rc = dev_alloc(c, &c->th_c, ncol_nodes * k + 2 * slack)) ||
           (rc = dev_alloc(c, &c->xrow_c, ncol_nodes)) || (rc = dev_alloc(c, &c->xcolT_r, nrow_nodes)) ||
           (rc = dev_alloc(c, &c->sendbuf, nrow_nodes + ncol_nodes)))
         return bail(rc);
@@ -514,7 +528,8 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
           ((rc = dev_alloc(c, &c->sendbuf_mu, (nrow_nodes + ncol_nodes) * k)) ||
            (rc = dev_alloc(c, &c->recvbuf_mu, (nrow_nodes + ncol_nodes) * k))))
         return bail(rc);
-      HIP_TRY_BAIL(hipMemset(c->th_c + ncol_nodes * k, 0, sizeof(float) * slack));
+      HIP_TRY_BAIL(hipMemset(c->th_c, 0, sizeof(float) * (ncol_nodes * k + 2 * slack)));
+      c->th_c += slack;
     }
     c->n_partial = 2048;
     if ((rc = dev_alloc(c, &c->d_partial, (size_t)c->n_partial * 2))) return bail(rc);
@@ -614,12 +629,15 @@ __global__ void chain_init_theta_kernel(float *__restrict__ th, long long n, flo
     th[i] = s / (rho * 2);
   }
 }
-__global__ void chain_init_w_kernel(float *Wsplit, float *Wt, const float *W, int n, float rho) {
+__global__ void chain_init_w_kernel(float *Wsplit, float *Wt, float *WsplitT, float *WtT, const float *W, int k, float rho) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
+  if (i < k * k) {
     const float ws = W[i] / rho;  // Grid.cpp:975-976
     Wsplit[i] = ws;
     Wt[i] = rho * ws;  // Tree.cpp:99
+    const int t = (i % k) * k + i / k;
+    WsplitT[t] = ws;
+    WtT[t] = rho * ws;
   }
 }
 }  // namespace
@@ -658,7 +676,7 @@ int admm_init(admm_ctx *c) {
       hipLaunchKernelGGL(fill_int_kernel, dim3(grid_for(nrow, 256)), dim3(256), 0, s, c->xcolT_r, nrow, -1);
       hipLaunchKernelGGL(fill_int_kernel, dim3(grid_for(ncol, 256)), dim3(256), 0, s, c->xrow_c, ncol, -1);
     }
-    hipLaunchKernelGGL(chain_init_w_kernel, dim3((d.k * d.k + 255) / 256), dim3(256), 0, s, c->d_Wsplit, c->d_Wt, c->d_W, d.k * d.k, d.rho);
+    hipLaunchKernelGGL(chain_init_w_kernel, dim3((d.k * d.k + 255) / 256), dim3(256), 0, s, c->d_Wsplit, c->d_Wt, c->d_WsplitT, c->d_WtT, c->d_W, d.k, d.rho);
     HIP_TRY(c, hipGetLastError());
   }
   HIP_TRY(c, hipStreamSynchronize(s));
@@ -1031,7 +1049,7 @@ static int chain_obj_partials(admm_ctx *c, double *primal, double *linear) {
 
 // slot[1] = pairwise term; the last sweep left it per chain in d_chain_lin.
 static int chain_pairwise_enqueue(admm_ctx *c, double *slot) {
-  const int n = c->d.batch * (c->st.nrows + c->st.ncols);
+  const int n = 2 * c->d.batch * (c->st.nrows + c->st.ncols);  // one term per half chain
   hipLaunchKernelGGL(linear_reduce_kernel, dim3(1), dim3(256), 0, c->stream, slot + 1, c->d_chain_lin, n, 1, 0);
   HIP_TRY(c, hipGetLastError());
   return ADMM_OK;
@@ -1040,7 +1058,7 @@ static int chain_pairwise_enqueue(admm_ctx *c, double *slot) {
 // slot[0] = unary term of the labels the last sweep started from (it left
 // them per chain in d_chain_unary).
 static int chain_unary_from_sweep(admm_ctx *c, double *slot) {
-  const int n = c->d.batch * (c->st.nrows + c->st.ncols);
+  const int n = 2 * c->d.batch * (c->st.nrows + c->st.ncols);  // one term per half chain
   hipLaunchKernelGGL(linear_reduce_kernel, dim3(1), dim3(256), 0, c->stream, slot, c->d_chain_unary, n, 1, 0);
   HIP_TRY(c, hipGetLastError());
   return ADMM_OK;

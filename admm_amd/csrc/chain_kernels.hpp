@@ -13,9 +13,20 @@
 // when a caller asks for it).  Only mu - m enters the formulas, and before
 // the first solve mu = m = 1/k (Tree.cpp:24-33), i.e. mu - m = 0: the label
 // -1 stands for that state and matches no lane.
-// The sweep itself (forward min-plus recursion with lowest-index
-// back-pointers, backtrack from the lowest argmin) has no counterpart in the
-// reference, whose only subproblem solver is the per-edge one in Tree.cpp.
+// The sweep itself has no counterpart in the reference, whose only subproblem
+// solver is the per-edge one in Tree.cpp.  A chain of T nodes is swept from
+// both ends towards the middle by two wavefronts of one workgroup: with
+// L = (T + 1) / 2,
+//   left   A_0 = t_0,          A_i[b] = t_i[b] + min_a (A_{i-1}[a] + W[a][b]),  i < L
+//   right  B_{T-1} = t_{T-1},  B_j[a] = t_j[a] + min_b (B_{j+1}[b] + W[a][b]),  j >= L
+//   join   J[a] = A_{L-1}[a] + min_b (B_L[b] + W[a][b])
+// every minimum remembering the lowest index that attains it.  x_{L-1} is the
+// lowest argmin of J and x_L its remembered b; the left half is traced back
+// from x_{L-1}, the right half forward from x_L.  The right half is the same
+// recursion as the left one on the reversed chain with the transposed table,
+// so one code path serves both; the halves meet through LDS and two workgroup
+// barriers.  Halving the serial length of a chain is what keeps the machine
+// busy when chains are scarce (small grids, one strip of many).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -35,10 +46,11 @@ struct ChainSeg {
   float *lam;          // Lagrange multipliers of these chains
   int *x;              // [nchains][T] labels of these chains (-1 before the first solve)
   const int *xo;       // [nchains][T] labels the crossing chains gave the same nodes
-  uint8_t *bp;         // [nchains][T][KP] back-pointer scratch
+  uint8_t *bp;         // [nchains][2][half length padded to 64][KP] back-pointer scratch
   float *chain_min;    // [nchains] (dual evaluation only)
-  double *chain_lin;   // [nchains] pairwise energy of the chain's new labels: sum of (W / rho)[x_t][x_t+1]
-  double *chain_unary; // [nchains] unary energy of the labels the sweep started from: sum of theta_share[x_t]
+  double *chain_lin;   // [nchains][2] pairwise energy of the new labels per half chain: sum of (W / rho)[x_t][x_t+1]
+                       //              (the edge between the halves counts with the right half)
+  double *chain_unary; // [nchains][2] unary energy of the labels the sweep started from: sum of theta_share[x_t]
   int nchains;
   int T;
   int cpg;
@@ -48,15 +60,17 @@ struct ChainSeg {
 struct ChainArgs {
   ChainSeg seg[2];
   int nseg;
-  int wave_begin[3];  // waves [wave_begin[i], wave_begin[i+1]) work on seg[i]
+  int wave_begin[3];  // waves [wave_begin[i], wave_begin[i+1]) work on seg[i]; even, since
+                      // waves 2p and 2p+1 are the left and the right half of the same chains
   int k;
   float penalty, rho, inv_k;
   const float *Wt;     // k*k, rho * (W / rho)
   const float *Wsplit; // k*k, W / rho
+  const float *WtT, *WsplitT;  // their transposes, for the right halves
   unsigned long long *stamps;  // diagnostics: 3 clock reads per wavefront, or null
 };
 
-constexpr int kChainBlock = 256;  // 4 independent wavefronts per workgroup
+constexpr int kChainBlock = 256;  // two pairs of wavefronts per workgroup (a pair = the two halves of the same chains)
 constexpr int kChunk = 64;        // steps whose back-pointers are staged in LDS
 
 __device__ __forceinline__ float chain_mu(int x, int l, float inv_k) {
@@ -163,7 +177,9 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   constexpr int MROW = CPW * KP + 64;
 
   __shared__ __attribute__((aligned(16))) float s_M[WPB][NB * MROW];  // messages + a dump row
-  __shared__ __attribute__((aligned(16))) float s_W[RECOMP ? KP * WLD : 4];  // [target][source]
+  __shared__ __attribute__((aligned(16))) float s_W[2][RECOMP ? KP * WLD : 4];  // per direction: [target][source]
+  __shared__ float s_join[WPB / 2][CPW * KP];  // last message of the left halves
+  __shared__ int s_joinx[WPB / 2][CPW];        // label of the left halves' last node, from the join
   __shared__ int s_x[WPB][CPW][kChunk];
   __shared__ int s_xo[WPB][CPW][kChunk];
   __shared__ __attribute__((aligned(16))) uint32_t s_bp[WPB][CPW][16 * KP];
@@ -184,25 +200,39 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   const int s = within / KP;
   const int b = within % KP;
   const int k = args.k;
-  const int chain_raw = (wave - args.wave_begin[si]) * CPW + cs;
+  // waves 2p, 2p+1 of a segment: left and right half of the chains of group p
+  const int wlocal = wave - args.wave_begin[si];
+  const int rev = wlocal & 1;   // 1: the right half, swept from the chain's last node backwards
+  const int pair = wib >> 1;    // wave_begin is even, so the two halves sit in one workgroup
+  const int chain_raw = (wlocal >> 1) * CPW + cs;
   const bool cvalid = chain_raw < sg.nchains;
   const int chain = cvalid ? chain_raw : sg.nchains - 1;
-  const int T = sg.T;
+  const int Tfull = sg.T;
+  const int Lhalf = (Tfull + 1) >> 1;
+  const int T = rev ? Tfull - Lhalf : Lhalf;  // steps of this half (the right half of a 1-node chain has none)
+  const int xdir = rev ? -1 : 1;
   const bool bvalid = b < k;
   const bool lvalid = cvalid && bvalid;
-  const long long first = (long long)(chain / sg.cpg) * sg.gstride + (long long)(chain % sg.cpg) * sg.cstride;
+  // first node of this half's sweep: the chain's node 0, or its node T-1
+  const long long half_first = rev ? (long long)(Tfull - 1) * sg.sstride : 0;
+  const long long first = (long long)(chain / sg.cpg) * sg.gstride + (long long)(chain % sg.cpg) * sg.cstride + half_first;
+  // the same for the wavefront's first chain: wave-uniform, no later chain lies below it
+  const int chain0 = (wlocal >> 1) * CPW;
+  const long long first0 = (long long)(chain0 / sg.cpg) * sg.gstride + (long long)(chain0 % sg.cpg) * sg.cstride + half_first;
   const float INF = __builtin_inff();
   const float pen = args.penalty, rho = args.rho;
   // mu - m is (mu_own - mu_other) / 2, one of -1/2, 0, +1/2, so penalty * (mu - m)
   // is +-hpen or 0 with hpen = penalty / 2 (exact scaling by a power of two)
   const float hpen = pen * 0.5f;
 
-  // pairwise column of this lane's target label, kept in registers
+  // pairwise column of this lane's target label, kept in registers; the
+  // right half runs on the transposed table (source = label of the later node)
+  const float *__restrict__ Wuse = rev ? args.WtT : args.Wt;
   float Wr[A];
 #pragma unroll
   for (int j = 0; j < A; j++) {
     const int a = s * A + j;
-    Wr[j] = (a < k && bvalid) ? args.Wt[a * k + b] : INF;
+    Wr[j] = (a < k && bvalid) ? Wuse[a * k + b] : INF;
   }
 
   if constexpr (RECOMP) {
@@ -210,23 +240,43 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     // no block-wide barrier is needed before its own reads
     for (int i = lane; i < KP * KP; i += 64) {
       const int bb = i / KP, a = i % KP;
-      s_W[bb * WLD + a] = (a < k && bb < k) ? args.Wt[a * k + bb] : INF;
+      s_W[rev][bb * WLD + a] = (a < k && bb < k) ? Wuse[a * k + bb] : INF;
     }
     wave_lds_fence();
   }
 
-  // Addresses: a per-chain base pointer (wave-uniform when the wavefront holds
-  // one chain) plus a 32-bit element offset.  Operand loads are never
-  // predicated: steps past the chain's end and labels past k read the slack
-  // that follows every operand array, and their values are never used.
+  // Addresses: the operand arrays are read and written through buffer
+  // descriptors whose base is the lowest address this half chain touches; a
+  // step's position is a scalar byte offset and the lane's share a 32-bit
+  // offset that never changes, so the sweep spends no vector instruction on
+  // addressing.  Operand loads are never predicated: steps past the half
+  // chain's end and labels past k read the other half or the slack around every
+  // operand array, and their values are never used.
+  // A group of NS steps starting at step tg lies at the uniform signed offset
+  // tg * sdir + adj from the half's first node, and inside it lane s holds
+  // step tg + s at the non-negative offset lane_off (towards lower addresses
+  // when the half runs backwards, hence the mirrored s).
   const unsigned nstride = (unsigned)(sg.sstride * (long long)k);
-  const float *__restrict__ th_c = sg.theta + first * k;
-  float *lam_c = sg.lam + first * k;
-  const unsigned lane_off = (unsigned)s * nstride + (unsigned)b;  // own step of group 0
-  int *xchain = sg.x + (long long)chain * T;
-  const int *xochain = DUAL ? nullptr : sg.xo + (long long)chain * T;
+  // byte offset of the group that starts at step tg: soff0 + tg * sstep, modulo 2^32
+  // (the host checks that a half chain's span, slack included, stays below 4 GiB)
+  const unsigned reach = (unsigned)T + 96u;  // steps a backward half may touch, prefetch overrun included
+  const unsigned sstep = rev ? 0u - 4u * nstride : 4u * nstride;
+  const unsigned soff0 = rev ? 4u * nstride * (reach - (unsigned)(NS - 1)) : 0u;
+  const long long base_el = first0 * k - (rev ? (long long)reach * nstride : 0);
+  constexpr int kRsrcWord3 = 0x00020000;  // raw buffer of dwords
+  const __amdgpu_buffer_rsrc_t th_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sg.theta + base_el), 0, 0xFFFFFFFF, kRsrcWord3);
+  const __amdgpu_buffer_rsrc_t lam_rs = __builtin_amdgcn_make_buffer_rsrc(sg.lam + base_el, 0, 0xFFFFFFFF, kRsrcWord3);
+  // the lane's own step of group 0, in bytes
+  const unsigned lane_off = 4u * ((unsigned)((first - first0) * k) + (unsigned)(rev ? NS - 1 - s : s) * nstride + (unsigned)b);
+  auto buf_load = [&](const __amdgpu_buffer_rsrc_t &r, unsigned soff) -> float {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_off, soff, 0));
+  };
+  // labels of the half in sweep order: xchain[xdir * step]
+  int *xchain = sg.x + (long long)chain * Tfull + (rev ? Tfull - 1 : 0);
+  const int *xochain = DUAL ? nullptr : sg.xo + (long long)chain * Tfull + (rev ? Tfull - 1 : 0);
   const int Tpad = (T + kChunk - 1) / kChunk * kChunk;
-  uint32_t *bpchain = DUAL ? nullptr : reinterpret_cast<uint32_t *>(sg.bp) + (long long)chain * (Tpad / 4) * KP;
+  const int TpadH = (Lhalf + kChunk - 1) / kChunk * kChunk;  // scratch per half chain, in steps
+  uint32_t *bpchain = DUAL ? nullptr : reinterpret_cast<uint32_t *>(sg.bp) + ((long long)chain * 2 + rev) * (TpadH / 4) * KP;
 
   float *Mrow = &s_M[wib][cs * KP];
   // where this lane's M_new goes at sub-step u: the real slot when the lane
@@ -238,15 +288,15 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   float pth[GPB], plam[GPB];
 #pragma unroll
   for (int j = 0; j < GPB; j++) {
-    const unsigned off = lane_off + (unsigned)(j * NS) * nstride;
-    pth[j] = th_c[off];
-    plam[j] = lam_c[off];
+    const unsigned soff = soff0 + (unsigned)(j * NS) * sstep;
+    pth[j] = buf_load(th_rs, soff);
+    plam[j] = buf_load(lam_rs, soff);
   }
   int xnext = -1, xonext = -1;  // labels of the next 64-step chunk, in flight
   if (!DUAL) {
     for (int i = within; i < kChunk; i += LPC) {
-      s_x[wib][cs][i] = (i < T) ? xchain[i] : -1;
-      s_xo[wib][cs][i] = (i < T) ? xochain[i] : -1;
+      s_x[wib][cs][i] = (i < T) ? xchain[xdir * i] : -1;
+      s_xo[wib][cs][i] = (i < T) ? xochain[xdir * i] : -1;
     }
   }
 
@@ -282,7 +332,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         best_pend = best_prev;
         // the step's messages are still in the row it read them from
         m4_pend = *reinterpret_cast<const f4_t *>(&s_M[wib][(SBP & 1) * MROW + cs * KP + 4 * grp_pend]);
-        w4_pend = *reinterpret_cast<const f4_t *>(&s_W[b * WLD + 4 * grp_pend]);
+        w4_pend = *reinterpret_cast<const f4_t *>(&s_W[rev][b * WLD + 4 * grp_pend]);
       }
     }
   };
@@ -345,7 +395,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       const int tg = tb + j * NS;
       const bool glive = FULL || tg < T;
       const float th_in = pth[j], lam_in = plam[j];
-      const size_t goff = (size_t)(unsigned)tg * nstride;  // uniform
+      const unsigned goff = soff0 + (unsigned)tg * sstep;  // uniform
       float th_own = INF;
       if (DUAL) {
         th_own = th_in + lam_in;
@@ -357,7 +407,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         // in a register here, which saves the backtrack a gather per node.
         unary_acc += (xown == b) ? (double)th_in : 0.0;
         const float la = lam_in + p;                          // Tree.cpp:70
-        if (lvalid && (FULL || tg + s < T)) (lam_c + goff)[lane_off] = la;
+        if (lvalid && (FULL || tg + s < T)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(la), lam_rs, lane_off, goff, 0);
         th_own = rho * (th_in + la) + p;                      // Tree.cpp:85-86
       }
       if (!bvalid) th_own = INF;
@@ -384,9 +434,9 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
             xown = s_x[wib][cs][tt0 + (j + 1) * NS + s];
             xoth = s_xo[wib][cs][tt0 + (j + 1) * NS + s];
           }
-          const size_t poff = goff + (size_t)BLK * nstride;
-          pth[j] = (th_c + poff)[lane_off];
-          plam[j] = (lam_c + poff)[lane_off];
+          const unsigned poff = goff + (unsigned)BLK * sstep;
+          pth[j] = buf_load(th_rs, poff);
+          plam[j] = buf_load(lam_rs, poff);
         }
         __builtin_amdgcn_sched_barrier(0);
         // (b) ... while the previous step's back-pointer is worked out
@@ -460,8 +510,8 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       // labels of chunk t0 are in LDS; fetch the next chunk's while this one runs
       if (LPC >= kChunk) {
         const bool ok = t0 + kChunk + within < T;
-        xnext = ok ? xchain[t0 + kChunk + within] : -1;
-        xonext = ok ? xochain[t0 + kChunk + within] : -1;
+        xnext = ok ? xchain[xdir * (t0 + kChunk + within)] : -1;
+        xonext = ok ? xochain[xdir * (t0 + kChunk + within)] : -1;
       }
     }
     if (t0 + kChunk <= T) {
@@ -479,8 +529,8 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       } else {
         for (int i = within; i < kChunk; i += LPC) {
           const bool ok = t0 + kChunk + i < T;
-          s_x[wib][cs][i] = ok ? xchain[t0 + kChunk + i] : -1;
-          s_xo[wib][cs][i] = ok ? xochain[t0 + kChunk + i] : -1;
+          s_x[wib][cs][i] = ok ? xchain[xdir * (t0 + kChunk + i)] : -1;
+          s_xo[wib][cs][i] = ok ? xochain[xdir * (t0 + kChunk + i)] : -1;
         }
       }
       wave_lds_fence();
@@ -497,26 +547,77 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     finish(std::integral_constant<int, BLK - 1>{}, tb_last, tb_last + BLK - 1 < T);
   }
 
-  // lowest-index argmin of the last message, inside each chain's KP lanes
+  // ---- the two halves meet ----
+  // The left half publishes its last message; the right half adds one more
+  // min-plus step towards it (no unary), takes the lowest argmin of the sum
+  // and hands the left half its last label.  Every wavefront of the
+  // workgroup passes the same two barriers (one that has already returned is
+  // not waited for).
   wave_lds_fence();
-  float bv = Mrow[(RECOMP ? (T & 1) * MROW : 0) + b];  // step T-1 wrote row T & 1
+  const float *Mlast = Mrow + (RECOMP ? (T & 1) * MROW : 0);  // step T-1 wrote row T & 1
+  float bv = Mlast[b];
   int bi = b;
+  const bool two = Tfull > Lhalf;  // the chain has a right half
+  if (!rev) s_join[pair][cs * KP + b] = bv;  // the NS lanes of a label write the same value
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  // lowest-index argmin of (bv, bi) inside each chain's KP lanes
+  auto chain_argmin = [&]() {
 #pragma unroll
-  for (int d = 1; d < KP; d <<= 1) {
-    const float ov = __shfl_xor(bv, d);
-    const int oi = __shfl_xor(bi, d);
-    const bool take = (ov < bv) || (ov == bv && oi < bi);
-    bv = take ? ov : bv;
-    bi = take ? oi : bi;
+    for (int d = 1; d < KP; d <<= 1) {
+      const float ov = __shfl_xor(bv, d);
+      const int oi = __shfl_xor(bi, d);
+      const bool take = (ov < bv) || (ov == bv && oi < bi);
+      bv = take ? ov : bv;
+      bi = take ? oi : bi;
+    }
+  };
+  int xjoin = 0;  // right half: the label the join gives the left half's last node
+  if (rev && two) {
+    // g = min over this lane's sources of (B_L[src] + W[b][src]), lowest src first
+    float gbest = INF;
+    int garg = 0;
+#pragma unroll
+    for (int j = 0; j < A; j++) {
+      const float cnd = Mlast[s * A + j] + Wr[j];
+      if (cnd < gbest) { gbest = cnd; garg = s * A + j; }
+    }
+#pragma unroll
+    for (int d = KP; d < LPC; d <<= 1) {
+      const float ob = __shfl_xor(gbest, d);
+      const int oa = __shfl_xor(garg, d);
+      const bool take = (ob < gbest) || (ob == gbest && oa < garg);
+      gbest = take ? ob : gbest;
+      garg = take ? oa : garg;
+    }
+    bv = bvalid ? s_join[pair][cs * KP + b] + gbest : INF;  // J[b]
+    chain_argmin();
+    xjoin = bi;
+    if (within == 0) s_joinx[pair][cs] = xjoin;
+    bi = __shfl(garg, cs * LPC + xjoin);  // label of the right half's last node: where its trace starts
+  } else {
+    chain_argmin();  // a chain of one node: the left half's own argmin decides
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (!rev && two) bi = s_joinx[pair][cs];
   if (DUAL) {
-    if (cvalid && within == 0) sg.chain_min[chain] = bv;
+    // the chain minimum is the join's (or, for one node, the left half's)
+    if (cvalid && within == 0 && (two ? rev : !rev)) sg.chain_min[chain] = bv;
     return;
   }
 
 #pragma unroll
   for (int d = 1; d < LPC; d <<= 1) unary_acc += __shfl_xor(unary_acc, d);
-  if (cvalid && within == 0) sg.chain_unary[chain] = unary_acc;
+  if (cvalid && within == 0) sg.chain_unary[2 * chain + rev] = unary_acc;
+  if (T == 0) {  // right half of a one-node chain: nothing to trace
+    if (cvalid && within == 0) sg.chain_lin[2 * chain + rev] = 0.0;
+    return;
+  }
+  const float *__restrict__ Wsp = rev ? args.WsplitT : args.Wsplit;
+  const int Tedge = T + rev;  // the right half also owns the edge to the left half's last node
   if (args.stamps && lane == 0) {
     args.stamps[3 * (size_t)wave] = st0;
     args.stamps[3 * (size_t)wave + 1] = __builtin_readcyclecounter();
@@ -545,13 +646,13 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
 #pragma unroll
     for (int q = 0; q < CPW; q++) {
       curs[q] = q * LPC + __builtin_amdgcn_readlane(bi, q * LPC);  // lane holding the chain's last label
-      carry[q] = 0;
+      carry[q] = __builtin_amdgcn_readlane(xjoin, q * LPC);  // used by the right half only
       linc[q] = 0.0;
       wp[q] = 0.0f;
-      const int craw = (wave - args.wave_begin[si]) * CPW + q;
+      const int craw = (wlocal >> 1) * CPW + q;
       cval[q] = craw < sg.nchains;
       const int cq = cval[q] ? craw : sg.nchains - 1;
-      xcb[q] = sg.x + (long long)cq * T;
+      xcb[q] = sg.x + (long long)cq * Tfull + (rev ? Tfull - 1 : 0);
     }
     // back-pointers are fetched two chunks ahead of the walk (bpr: this chunk,
     // bpn: the next one, bpf: in flight); scheduling barriers keep the loads
@@ -641,14 +742,14 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         xn = (lane == n - 1) ? carry[q] : xn;
         const int t = t0 + lane;
         if (n == kChunk && cval[q]) {
-          xcb[q][t] = xi;
-          const float wv = args.Wsplit[xi * k + xn];
-          wp[q] = (t + 1 < T) ? wv : 0.0f;
+          xcb[q][xdir * t] = xi;
+          const float wv = Wsp[xi * k + xn];
+          wp[q] = (t + 1 < Tedge) ? wv : 0.0f;
         } else {
           wp[q] = 0.0f;
           if (lane < n) {
-            if (cval[q]) xcb[q][t] = xi;
-            if (t + 1 < T) wp[q] = args.Wsplit[xi * k + xn];
+            if (cval[q]) xcb[q][xdir * t] = xi;
+            if (t + 1 < Tedge) wp[q] = Wsp[xi * k + xn];
           }
         }
         carry[q] = __builtin_amdgcn_readlane(xi, 0);
@@ -664,7 +765,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       double l = linc[q] + (double)wp[q];
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) l += __shfl_xor(l, d);
-      if (cval[q] && lane == 0) sg.chain_lin[(wave - args.wave_begin[si]) * CPW + q] = l;
+      if (cval[q] && lane == 0) sg.chain_lin[2 * ((wlocal >> 1) * CPW + q) + rev] = l;
     }
     if (args.stamps && lane == 0) args.stamps[3 * (size_t)wave + 2] = __builtin_readcyclecounter();
     return;
@@ -697,7 +798,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   float wp[DEFER ? NI : 1];
 #pragma unroll
   for (int q = 0; q < (DEFER ? NI : 1); q++) wp[q] = 0.0f;
-  int carry = 0;  // label of the first node after the current chunk
+  int carry = xjoin;  // label of the first node after the current chunk (right half: the left half's last node)
   fetch_chunk(nchunks - 1);
   for (int ci = nchunks - 1; ci >= 0; ci--) {
     const int t0 = ci * kChunk;
@@ -741,12 +842,12 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       const int i = within + q * LPC;
       if (i < n) {
         const int xi = s_x[wib][cs][i];
-        if (cvalid) xchain[t0 + i] = xi;
+        if (cvalid) xchain[xdir * (t0 + i)] = xi;
         const int t = t0 + i;
         float wv = 0.0f;
-        if (t + 1 < T) {
+        if (t + 1 < Tedge) {
           const int xn = (i + 1 < n) ? s_x[wib][cs][i + 1] : carry;
-          wv = args.Wsplit[xi * k + xn];
+          wv = Wsp[xi * k + xn];
         }
         if (DEFER) wp[q] = wv;
         else lin += (double)wv;
@@ -763,7 +864,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   }
 #pragma unroll
   for (int d = 1; d < LPC; d <<= 1) lin += __shfl_xor(lin, d);
-  if (cvalid && within == 0) sg.chain_lin[chain] = lin;
+  if (cvalid && within == 0) sg.chain_lin[2 * chain + rev] = lin;
   if (args.stamps && lane == 0) args.stamps[3 * (size_t)wave + 2] = __builtin_readcyclecounter();
 }
 

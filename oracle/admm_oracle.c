@@ -273,12 +273,19 @@ float *oracle_edge_vertmu(oracle_edge *o) { return o->vertMu; }
  *   adjust    t = rho*(theta_tau + lambda) - penalty*(m - mu)     (Tree.cpp:85-86)
  *             pairwise = rho * W_tau                              (Tree.cpp:99)
  *   consensus m_v = (mu_row + mu_col) / 2                         (Grid.cpp:176-180)
- * and the subproblem is min-sum: forward
- *   M_0 = t_0,  M_{t+1}[b] = t_{t+1}[b] + min_a (M_t[a] + W[a][b]),
- * back-pointer = lowest a attaining the minimum, backtrack from the lowest
- * argmin of the last M.  mu is the one-hot vector of the chain's labels
- * (before the first solve it is the uniform 1/k of Tree.cpp:24-33, kept as the
- * label -1).
+ * and the subproblem is min-sum on a chain of T nodes, swept from both ends
+ * towards the middle (the two halves are independent until they meet, which
+ * is what lets two wavefronts share a chain).  With L = (T + 1) / 2:
+ *   left   A_0 = t_0,          A_i[b] = t_i[b] + min_a (A_{i-1}[a] + W[a][b]),  i < L
+ *   right  B_{T-1} = t_{T-1},  B_j[a] = t_j[a] + min_b (B_{j+1}[b] + W[a][b]),  j >= L
+ *   join   J[a] = A_{L-1}[a] + min_b (B_L[b] + W[a][b])
+ * Every minimum remembers the lowest index attaining it.  x_{L-1} = lowest
+ * argmin of J, x_L = its remembered b; the left half is traced back from
+ * x_{L-1}, the right half forward from x_L.  T = 1 has no right half and
+ * x_0 = lowest argmin of A_0.  Each candidate is one rounded add and each
+ * message one more rounded add, in exactly this association.
+ * mu is the one-hot vector of the chain's labels (before the first solve it
+ * is the uniform 1/k of Tree.cpp:24-33, kept as the label -1).
  */
 struct oracle_chain {
   int R, C, k;
@@ -342,6 +349,80 @@ static inline float chain_mu(int x, int l, float inv_k) {
   return x < 0 ? inv_k : (x == l ? 1.0f : 0.0f);
 }
 
+/* min over src of (M[src] + W[...]) with the lowest src attaining it.
+ * transposed = 0: W[src][tgt] (left half); 1: W[tgt][src] (right half, join). */
+static inline float minplus(const float *M, const float *W, int k, int tgt, int transposed, int *arg) {
+  float best = M[0] + (transposed ? W[tgt * k] : W[tgt]);
+  int at = 0;
+  for (int s = 1; s < k; s++) {
+    float c = M[s] + (transposed ? W[tgt * k + s] : W[s * k + tgt]);
+    if (c < best) { best = c; at = s; }
+  }
+  *arg = at;
+  return best;
+}
+
+/* Min-sum over a chain whose adjusted unaries are th[T][k], pairwise W[a][b]
+ * (a = label of the earlier node).  M: 3k floats of scratch.  ptr (T*k bytes)
+ * and x (T labels, node t at x[t * xstep]) may both be NULL when only the
+ * minimum is wanted.  ptr[t][.] holds, for t < L, the back-pointers of node t
+ * and, for t >= L, for every label of node t-1 the best label of node t.
+ * Returns min_a J[a]. */
+static float chain_minsum(const float *th, const float *W, int k, int T, float *M,
+                          unsigned char *ptr, int *x, long long xstep) {
+  const int L = (T + 1) / 2;
+  float *A = M, *B = M + k, *N = M + 2 * k;
+  int arg;
+  for (int b = 0; b < k; b++) A[b] = th[b];
+  for (int t = 1; t < L; t++) {
+    for (int b = 0; b < k; b++) {
+      float best = minplus(A, W, k, b, 0, &arg);
+      N[b] = th[(size_t)t * k + b] + best;
+      if (ptr) ptr[(size_t)t * k + b] = (unsigned char)arg;
+    }
+    memcpy(A, N, sizeof(float) * (size_t)k);
+  }
+  int xl = 0, xr = 0;
+  float value;
+  if (T - L > 0) {
+    for (int a = 0; a < k; a++) B[a] = th[(size_t)(T - 1) * k + a];
+    for (int t = T - 2; t >= L; t--) {
+      for (int a = 0; a < k; a++) {
+        float best = minplus(B, W, k, a, 1, &arg);
+        N[a] = th[(size_t)t * k + a] + best;
+        if (ptr) ptr[(size_t)(t + 1) * k + a] = (unsigned char)arg;
+      }
+      memcpy(B, N, sizeof(float) * (size_t)k);
+    }
+    /* join: N[a] = A[a] + min_b (B[b] + W[a][b]) */
+    int g0 = 0;
+    for (int a = 0; a < k; a++) {
+      float best = minplus(B, W, k, a, 1, &arg);
+      N[a] = A[a] + best;
+      if (ptr) ptr[(size_t)L * k + a] = (unsigned char)arg;
+      if (a == 0 || N[a] < N[xl]) { xl = a; g0 = arg; }
+    }
+    xr = g0;
+    value = N[xl];
+  } else {
+    for (int b = 1; b < k; b++) if (A[b] < A[xl]) xl = b;
+    value = A[xl];
+  }
+  if (x && ptr) {
+    int cur = xl;
+    for (int t = L - 1; t >= 0; t--) {
+      x[(long long)t * xstep] = cur;
+      if (t > 0) cur = ptr[(size_t)t * k + cur];
+    }
+    cur = xr;
+    for (int t = L; t < T; t++) {
+      x[(long long)t * xstep] = cur;
+      if (t + 1 < T) cur = ptr[(size_t)(t + 1) * k + cur];
+    }
+  }
+  return value;
+}
+
 /* One chain of T nodes; node t is first + t*step. */
 static void chain_solve(oracle_chain *o, float *lam, int *x, long long first,
                         long long step, int T, float *th, float *M, unsigned char *bp) {
@@ -357,27 +438,7 @@ static void chain_solve(oracle_chain *o, float *lam, int *x, long long first,
       th[(size_t)t * k + l] = o->rho * (o->theta[n * k + l] + la) - o->penalty * (mv - mu);
     }
   }
-  float *Mn = M + k;
-  for (int b = 0; b < k; b++) M[b] = th[b];
-  for (int t = 1; t < T; t++) {
-    for (int b = 0; b < k; b++) {
-      float best = M[0] + o->Wt[b];
-      int arg = 0;
-      for (int a = 1; a < k; a++) {
-        float c = M[a] + o->Wt[a * k + b];
-        if (c < best) { best = c; arg = a; }
-      }
-      Mn[b] = th[(size_t)t * k + b] + best;
-      bp[(size_t)t * k + b] = (unsigned char)arg;
-    }
-    memcpy(M, Mn, sizeof(float) * (size_t)k);
-  }
-  int cur = 0;
-  for (int b = 1; b < k; b++) if (M[b] < M[cur]) cur = b;
-  for (int t = T - 1; t >= 0; t--) {
-    x[first + (long long)t * step] = cur;
-    if (t > 0) cur = bp[(size_t)t * k + cur];
-  }
+  chain_minsum(th, o->Wt, k, T, M, bp, x + first, step);
 }
 
 static int g_threads = 1;
@@ -393,7 +454,7 @@ void oracle_chain_compute_range(oracle_chain *o, int r0, int r1, int c0, int c1)
 #endif
   {
     float *th = falloc((long long)T * k);
-    float *M = falloc(2LL * k);
+    float *M = falloc(3LL * k);
     unsigned char *bp = (unsigned char *)malloc((size_t)T * k + 1);
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 4) nowait
@@ -466,33 +527,24 @@ void oracle_chain_objective(const oracle_chain *o, double *primal, double *dual,
     *linear = p * o->rho;
   }
   if (dual) {
+    /* sum over chains of the chain minimum under theta_tau + lambda_tau */
     double d = 0.0;
-    float *M = falloc(2LL * k);
-    float *Mn = M + k;
+    const int Tmax = R > C ? R : C;
+    float *M = falloc(3LL * k);
+    float *th = falloc((long long)Tmax * k);
     for (int pass = 0; pass < 2; pass++) {
       const float *lam = pass == 0 ? o->lam_row : o->lam_col;
       int nch = pass == 0 ? R : C, T = pass == 0 ? C : R;
       for (int ch = 0; ch < nch; ch++) {
         long long first = pass == 0 ? (long long)ch * C : ch, step = pass == 0 ? 1 : C;
-        for (int b = 0; b < k; b++) M[b] = o->theta[first * k + b] + lam[first * k + b];
-        for (int t = 1; t < T; t++) {
+        for (int t = 0; t < T; t++) {
           long long n = first + (long long)t * step;
-          for (int b = 0; b < k; b++) {
-            float best = M[0] + o->Wsplit[b];
-            for (int a = 1; a < k; a++) {
-              float c = M[a] + o->Wsplit[a * k + b];
-              if (c < best) best = c;
-            }
-            Mn[b] = (o->theta[n * k + b] + lam[n * k + b]) + best;
-          }
-          memcpy(M, Mn, sizeof(float) * (size_t)k);
+          for (int b = 0; b < k; b++) th[(size_t)t * k + b] = o->theta[n * k + b] + lam[n * k + b];
         }
-        float best = M[0];
-        for (int b = 1; b < k; b++) if (M[b] < best) best = M[b];
-        d += (double)best;
+        d += (double)chain_minsum(th, o->Wsplit, k, T, M, NULL, NULL, 0);
       }
     }
-    free(M);
+    free(M); free(th);
     *dual = d * o->rho;
   }
 }

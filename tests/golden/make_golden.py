@@ -88,6 +88,13 @@ def chain_case(name, R, C, k, iters, pairwise, seed=1234):
 
 
 if __name__ == "__main__":
+    if sys.argv[1:] == ["chain"]:  # only the vectors of this repository's own chain restatement
+        chain_case("chain_12x17_k4_potts.npz", 12, 17, 4, 30, "potts")
+        chain_case("chain_20x9_k16_trunc.npz", 20, 9, 16, 20, "trunc_linear")
+        chain_case("chain_10x70_k32_dense.npz", 10, 70, 32, 15, "dense")
+        chain_case("chain_7x5_k5_dense.npz", 7, 5, 5, 20, "dense")
+        chain_case("chain_2x1_k3_dense.npz", 2, 1, 3, 8, "dense")
+        raise SystemExit(0)
     objs = edge_case("edge_3x3_k2.npz", 3, 3, 2, 3, dump_at=(1, 2, 3))
     print("3x3 k=2:", ["%.9f" % x for x in objs])
     objs = edge_case("edge_8x8_k4.npz", 8, 8, 4, 40, dump_at=(40,))
@@ -99,6 +106,7 @@ if __name__ == "__main__":
     chain_case("chain_20x9_k16_trunc.npz", 20, 9, 16, 20, "trunc_linear")
     chain_case("chain_10x70_k32_dense.npz", 10, 70, 32, 15, "dense")
     chain_case("chain_7x5_k5_dense.npz", 7, 5, 5, 20, "dense")
+    chain_case("chain_2x1_k3_dense.npz", 2, 1, 3, 8, "dense")  # chains of one and two nodes
     known = {
         "source": "totalObj lines printed by the unmodified reference binary (admm.cpp:97-99), "
                   "synthetic grid, LCG seed 1234, Potts 0.5, penalties (0.5, 1.0), 1 rank",

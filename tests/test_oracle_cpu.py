@@ -156,7 +156,7 @@ def test_chain_oracle_against_brute_force():
     """Viterbi with lowest-index ties against exhaustive search on tiny chains."""
     import itertools
     rng = np.random.default_rng(11)
-    for k, T in ((2, 5), (3, 4), (4, 3)):
+    for k, T in ((2, 5), (3, 4), (4, 3), (3, 1), (3, 2), (2, 9), (3, 6), (2, 10), (5, 3)):
         # quantised costs so that exact ties occur
         un = (rng.integers(0, 4, size=(1, T, k)) * 0.25).astype(np.float32)
         W = (rng.integers(0, 3, size=(k, k)) * 0.25).astype(np.float32)
