@@ -298,11 +298,23 @@ int chain_consensus(admm_ctx *c, float *m, const int *xa, const int *xbT, int nr
   return ADMM_OK;
 }
 
-int transpose_labels(admm_ctx *c, int *out, const int *in, int nr, int nc) {
-  if (nr <= 0 || nc <= 0) return ADMM_OK;
-  const int tr = (nr + 31) / 32, tc = (nc + 31) / 32;
-  const long long blocks = (long long)c->d.batch * tr * tc;
-  hipLaunchKernelGGL(transpose_labels_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, out, in, nr, nc, tc, tr * tc);
+// Both transpositions of Update in one launch: out0 = in0 (nr0 x nc0 per
+// grid) transposed, out1 = in1 (nr1 x nc1) transposed.
+int transpose_labels2(admm_ctx *c, int *out0, const int *in0, int nr0, int nc0, int *out1, const int *in1, int nr1, int nc1) {
+  TransposeArgs a{};
+  int blocks = 0;
+  auto add = [&](int *out, const int *in, int nr, int nc) {
+    if (nr <= 0 || nc <= 0) return;
+    TransposeJob &j = a.job[a.njobs++];
+    const int tr = (nr + 31) / 32, tc = (nc + 31) / 32;
+    j.out = out; j.in = in; j.nr = nr; j.nc = nc; j.tiles_c = tc; j.tiles_per_grid = tr * tc;
+    j.block_begin = blocks;
+    blocks += c->d.batch * tr * tc;
+  };
+  add(out0, in0, nr0, nc0);
+  add(out1, in1, nr1, nc1);
+  if (blocks == 0) return ADMM_OK;
+  hipLaunchKernelGGL(transpose_labels_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, a);
   HIP_TRY(c, hipGetLastError());
   return ADMM_OK;
 }
@@ -748,14 +760,10 @@ int pack_labels(admm_ctx *c, const ExchangePlan &p) {
   const admm_desc &d = c->d;
   const int nr = c->st.nrows, nc = c->st.ncols;
   int *send_a = c->sendbuf, *send_b = c->sendbuf + p.off_a[d.nranks];
-  for (int h = 0; h < d.nranks; h++) {
-    if (nr > 0 && p.nc[h] > 0)
-      hipLaunchKernelGGL(label_block_copy_kernel, dim3(grid_for((long long)nr * p.nc[h], 256)), dim3(256), 0, c->stream,
-                         send_a + p.off_a[h], (long long)p.nc[h], c->xrow_r + p.c0[h], (long long)d.cols, nr, p.nc[h]);
-    if (nc > 0 && p.nr[h] > 0)
-      hipLaunchKernelGGL(label_block_copy_kernel, dim3(grid_for((long long)nc * p.nr[h], 256)), dim3(256), 0, c->stream,
-                         send_b + p.off_b[h], (long long)p.nr[h], c->xcolT_c + p.r0[h], (long long)d.rows, nc, p.nr[h]);
-  }
+  const long long total = (long long)nr * d.cols + (long long)nc * d.rows;
+  if (total > 0)
+    hipLaunchKernelGGL(pack_strip_labels_kernel, dim3(grid_for(total, 256)), dim3(256), 0, c->stream, send_a, send_b,
+                       c->xrow_r, c->xcolT_c, nr, nc, d.rows, d.cols, d.nranks);
   if (d.exchange == ADMM_EXCHANGE_DENSE) {
     const long long n = p.off_a[d.nranks] + p.off_b[d.nranks];
     if (n > 0)
@@ -970,9 +978,8 @@ int admm_update(admm_ctx *c) {
   // The consensus of a node is a function of the two labels it received
   // (Grid.cpp:163-181 with one-hot marginals); the sweep evaluates it from
   // them, so Update only lays each set of labels out along the crossing chains.
-  if ((rc = transpose_labels(c, c->xo_r, c->xcolT_r, d.cols, c->st.nrows))) return rc;  // [cols][nrows] -> [nrows][cols]
-  if ((rc = transpose_labels(c, c->xo_c, c->xrow_c, d.rows, c->st.ncols))) return rc;   // [rows][ncols] -> [ncols][rows]
-  return ADMM_OK;
+  // [cols][nrows] -> [nrows][cols] and [rows][ncols] -> [ncols][rows]
+  return transpose_labels2(c, c->xo_r, c->xcolT_r, d.cols, c->st.nrows, c->xo_c, c->xrow_c, d.rows, c->st.ncols);
 }
 
 namespace {

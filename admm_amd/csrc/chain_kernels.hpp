@@ -990,12 +990,30 @@ __global__ __launch_bounds__(256) void chain_objective_kernel(
   }
 }
 
-// out[g][c][r] = in[g][r][c] for g < batch, r < nr, c < nc; 32 x 32 tiles through LDS.
-__global__ __launch_bounds__(256) void transpose_labels_kernel(int *__restrict__ out, const int *__restrict__ in,
-                                                               int nr, int nc, int tiles_c, int tiles_per_grid) {
+// One transposition: out[g][c][r] = in[g][r][c] for g < batch, r < nr, c < nc.
+struct TransposeJob {
+  int *out;
+  const int *in;
+  int nr, nc, tiles_c, tiles_per_grid;
+  int block_begin;  // first workgroup of this job
+};
+struct TransposeArgs {
+  TransposeJob job[2];
+  int njobs;
+};
+
+// Up to two transpositions in one launch (Update needs both label arrays laid
+// out along the crossing chains); 32 x 32 tiles through LDS.
+__global__ __launch_bounds__(256) void transpose_labels_kernel(const TransposeArgs args) {
   __shared__ int s_t[32][33];
-  const int g = blockIdx.x / tiles_per_grid;
-  const int tile = blockIdx.x % tiles_per_grid;
+  const int ji = (args.njobs > 1 && (int)blockIdx.x >= args.job[1].block_begin) ? 1 : 0;
+  const TransposeJob &jb = args.job[ji];
+  int *__restrict__ out = jb.out;
+  const int *__restrict__ in = jb.in;
+  const int nr = jb.nr, nc = jb.nc, tiles_c = jb.tiles_c, tiles_per_grid = jb.tiles_per_grid;
+  const int blk = blockIdx.x - jb.block_begin;
+  const int g = blk / tiles_per_grid;
+  const int tile = blk % tiles_per_grid;
   const int r0 = (tile / tiles_c) * 32, c0 = (tile % tiles_c) * 32;
   const long long base = (long long)g * nr * nc;
   for (int i = threadIdx.x; i < 1024; i += 256) {
@@ -1009,16 +1027,40 @@ __global__ __launch_bounds__(256) void transpose_labels_kernel(int *__restrict__
   }
 }
 
-// Strided gather / scatter of label blocks for the strip exchange.
-// dst[i][j] = src[(r0+i)*ld + c0 + j], i < nr, j < nc (pack), or the inverse.
-__global__ void label_block_copy_kernel(int *__restrict__ dst, long long dst_ld,
-                                        const int *__restrict__ src, long long src_ld, int nr,
-                                        int nc) {
-  const long long total = (long long)nr * nc;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+// Splits n items over G ranks as admm_partition does and returns the rank that
+// owns item i, with that rank's first item and count.
+__device__ __forceinline__ int owner_of(int i, int n, int G, int *start, int *count) {
+  const int base = n / G, extra = n % G;
+  const int cut = extra * (base + 1);
+  int h;
+  if (i < cut) { h = i / (base + 1); *start = h * (base + 1); *count = base + 1; }
+  else { h = extra + (i - cut) / base; *start = cut + (h - extra) * base; *count = base; }
+  return h;
+}
+
+// All send blocks of the strip exchange in one launch.  a-blocks: my
+// row-chain labels xrow[nr][cols] cut by the peers' column strips, block h =
+// [nr][nc_h]; b-blocks: my column-chain labels xcolT[nc][rows] cut by the
+// peers' row strips, block h = [nc][nr_h].  The blocks of a kind lie in rank
+// order, so block h of the a-kind starts at nr * c0_h and of the b-kind at
+// nc * r0_h.
+__global__ void pack_strip_labels_kernel(int *__restrict__ send_a, int *__restrict__ send_b,
+                                         const int *__restrict__ xrow, const int *__restrict__ xcolT,
+                                         int nr, int nc, int rows, int cols, int G) {
+  const long long na = (long long)nr * cols, nb = (long long)nc * rows;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < na + nb;
        i += (long long)gridDim.x * blockDim.x) {
-    const long long r = i / nc, c = i % nc;
-    dst[r * dst_ld + c] = src[r * src_ld + c];
+    int st, cnt;
+    if (i < na) {
+      const int r = (int)(i / cols), cidx = (int)(i % cols);
+      owner_of(cidx, cols, G, &st, &cnt);
+      send_a[(long long)nr * st + (long long)r * cnt + (cidx - st)] = xrow[i];
+    } else {
+      const long long j = i - na;
+      const int cc = (int)(j / rows), ridx = (int)(j % rows);
+      owner_of(ridx, rows, G, &st, &cnt);
+      send_b[(long long)nc * st + (long long)cc * cnt + (ridx - st)] = xcolT[j];
+    }
   }
 }
 
