@@ -256,6 +256,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // tg * sdir + adj from the half's first node, and inside it lane s holds
   // step tg + s at the non-negative offset lane_off (towards lower addresses
   // when the half runs backwards, hence the mirrored s).
+  constexpr int kRsrcWord3 = 0x00020000;  // raw buffer of dwords
   const unsigned nstride = (unsigned)(sg.sstride * (long long)k);
   // byte offset of the group that starts at step tg: soff0 + tg * sstep, modulo 2^32
   // (the host checks that a half chain's span, slack included, stays below 4 GiB)
@@ -263,11 +264,14 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   const unsigned sstep = rev ? 0u - 4u * nstride : 4u * nstride;
   const unsigned soff0 = rev ? 4u * nstride * (reach - (unsigned)(NS - 1)) : 0u;
   const long long base_el = first0 * k - (rev ? (long long)reach * nstride : 0);
-  constexpr int kRsrcWord3 = 0x00020000;  // raw buffer of dwords
   const __amdgpu_buffer_rsrc_t th_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sg.theta + base_el), 0, 0xFFFFFFFF, kRsrcWord3);
   const __amdgpu_buffer_rsrc_t lam_rs = __builtin_amdgcn_make_buffer_rsrc(sg.lam + base_el, 0, 0xFFFFFFFF, kRsrcWord3);
   // the lane's own step of group 0, in bytes
   const unsigned lane_off = 4u * ((unsigned)((first - first0) * k) + (unsigned)(rev ? NS - 1 - s : s) * nstride + (unsigned)b);
+  // Stores of lanes that own no label (padding past k, the duplicate of a
+  // clamped chain) get an offset beyond the descriptor's range, which the
+  // hardware drops: no branch around the store.
+  const unsigned lane_off_st = lvalid ? lane_off : 0xFFFFFFFFu;
   auto buf_load = [&](const __amdgpu_buffer_rsrc_t &r, unsigned soff) -> float {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_off, soff, 0));
   };
@@ -277,6 +281,11 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   const int Tpad = (T + kChunk - 1) / kChunk * kChunk;
   const int TpadH = (Lhalf + kChunk - 1) / kChunk * kChunk;  // scratch per half chain, in steps
   uint32_t *bpchain = DUAL ? nullptr : reinterpret_cast<uint32_t *>(sg.bp) + ((long long)chain * 2 + rev) * (TpadH / 4) * KP;
+  // the same scratch for the stores of the forward pass: descriptor at the
+  // wavefront's first chain, the lane's chain and label as a fixed offset
+  const __amdgpu_buffer_rsrc_t bp_rs = __builtin_amdgcn_make_buffer_rsrc(
+      DUAL ? nullptr : reinterpret_cast<uint32_t *>(sg.bp) + ((long long)chain0 * 2 + rev) * (TpadH / 4) * KP, 0, 0xFFFFFFFF, kRsrcWord3);
+  const unsigned bp_lane = lvalid ? 4u * ((unsigned)(chain - chain0) * 2u * (unsigned)(TpadH / 4) * KP + (unsigned)s * KP + (unsigned)b) : 0xFFFFFFFFu;
 
   float *Mrow = &s_M[wib][cs * KP];
   // where this lane's M_new goes at sub-step u: the real slot when the lane
@@ -374,7 +383,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       if (s == ((SBP >> 2) % NS)) keep = acc;
       if (((SBP >> 2) % NS) == NS - 1) {
         const int w0 = (tbp + SBP - (WIN - 1)) >> 2;  // first dword of the window
-        if (lvalid) bpchain[(long long)(w0 + s) * KP + b] = keep;
+        __builtin_amdgcn_raw_buffer_store_b32(keep, bp_rs, bp_lane, (unsigned)w0 * (4u * KP), 0);
       }
     }
   };
@@ -407,10 +416,9 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         // in a register here, which saves the backtrack a gather per node.
         unary_acc += (xown == b) ? (double)th_in : 0.0;
         const float la = lam_in + p;                          // Tree.cpp:70
-        if (lvalid && (FULL || tg + s < T)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(la), lam_rs, lane_off, goff, 0);
+        if (FULL || tg + s < T) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(la), lam_rs, lane_off_st, goff, 0);
         th_own = rho * (th_in + la) + p;                      // Tree.cpp:85-86
       }
-      if (!bvalid) th_own = INF;
       static_for<0, NS>([&](auto u_c) {
         constexpr int u = decltype(u_c)::value;
         const bool live = FULL || tg + u < T;
@@ -494,7 +502,8 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
 #pragma unroll
             for (int d = KP; d < LPC; d <<= 1) best = __builtin_fminf(best, __shfl_xor(best, d));
           }
-          if (j == 0 && u == 0) best = (tb == 0) ? 0.0f : best;  // M_0 = t_0
+          // M_0 = t_0; a lane past k starts at +inf and stays there (its pairwise column is +inf)
+          if (j == 0 && u == 0) best = (tb == 0) ? (bvalid ? 0.0f : INF) : best;
           const float Mnew = th_own + best;
           wave_lds_fence();
           s_M[wib][(RECOMP ? (((j * NS + u) & 1) ^ 1) * MROW : 0) + m_addr[u]] = Mnew;
@@ -515,7 +524,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       }
     }
     if (t0 + kChunk <= T) {
-#pragma unroll 1
+#pragma unroll 2
       for (int tt = 0; tt < kChunk; tt += BLK) block(t0 + tt, tt, std::true_type{});
     } else {
 #pragma unroll 1
