@@ -75,6 +75,7 @@ struct admm_ctx {
   double *d_chain_unary = nullptr;  // per chain: unary energy of the labels the last sweep started from
   bool lin_valid = false;
   int pending_slot = 0;             // queued objective whose unary term is still to come, or 0
+  int swept_slot = 0;               // queued objective whose unary term the last sweep left, unsummed, in d_chain_unary
   int *sendbuf = nullptr;
   float *sendbuf_mu = nullptr, *recvbuf_mu = nullptr;  // ADMM_EXCHANGE_DENSE: the same blocks as float k-vectors
   std::vector<float> h_unary_stage;
@@ -372,7 +373,7 @@ int check_ctx(admm_ctx *c) {
 // ====================================================================== C ABI
 
 static int flush_pending(admm_ctx *c);
-static int chain_unary_from_sweep(admm_ctx *c, double *slot);
+static int settle_swept(admm_ctx *c);
 
 extern "C" {
 
@@ -714,14 +715,17 @@ int admm_compute(admm_ctx *c) {
     c->prof_used++;
     HIP_TRY(c, hipEventRecord(e0, c->stream));
   }
+  // per-chain unary terms of an earlier sweep that nobody has summed yet: the
+  // sweep below overwrites them
+  if (is_chain(c) && (rc = settle_swept(c))) return rc;
   rc = is_chain(c) ? chain_sweep(c, false) : edge_compute(c);
   if (rc) return rc;
   if (is_chain(c) && c->pending_slot) {
-    // this sweep summed the unaries of the labels it started from: the
-    // missing term of the objective queued for the previous solve
-    const int slot = c->pending_slot;
+    // this sweep summed, per chain, the unaries of the labels it started from:
+    // the missing term of the objective queued for the previous solve.  The
+    // sum over chains rides along with the next queued objective's reduction.
+    c->swept_slot = c->pending_slot;
     c->pending_slot = 0;
-    if ((rc = chain_unary_from_sweep(c, c->d_obj_slots + 2 * (size_t)slot))) return rc;
   }
   c->lin_valid = true;
   if (c->prof) HIP_TRY(c, hipEventRecord(e1, c->stream));
@@ -1018,6 +1022,35 @@ __global__ __launch_bounds__(256) void linear_reduce_kernel(double *__restrict__
 }
 }  // namespace
 
+namespace {
+// Up to two sums in one launch, one workgroup each: dst[j][0] = sum of part[j][0..n[j]).
+struct Reduce2Args {
+  double *dst[2];
+  const double *part[2];
+  int n[2];
+};
+__global__ __launch_bounds__(1024) void linear_reduce2_kernel(const Reduce2Args a) {
+  __shared__ double s_red[16];
+  const int j = blockIdx.x;
+  const double *__restrict__ part = a.part[j];
+  const int n = a.n[j];
+  double l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0;
+  int i = threadIdx.x;
+  for (; i + 3 * 1024 < n; i += 4 * 1024) {
+    l0 += part[i]; l1 += part[i + 1024]; l2 += part[i + 2048]; l3 += part[i + 3072];
+  }
+  for (; i < n; i += 1024) l0 += part[i];
+  double l = wave_sum((l0 + l1) + (l2 + l3));
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = l;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; w++) t += s_red[w];
+    a.dst[j][0] = t;
+  }
+}
+}  // namespace
+
 // Queues the chain objective kernels; dst (device, 2 doubles) receives the
 // primal and the linear sums of this strip, not yet scaled by rho.
 static int chain_obj_enqueue(admm_ctx *c, double *dst) {
@@ -1054,19 +1087,32 @@ static int chain_obj_partials(admm_ctx *c, double *primal, double *linear) {
 // A queued or returned linear objective is slot[0] + slot[1]: the unary and
 // the pairwise energy of every chain's own labels (Grid.cpp:1665-1680).
 
-// slot[1] = pairwise term; the last sweep left it per chain in d_chain_lin.
+// slot[1] = pairwise term; the last sweep left it per half chain in
+// d_chain_lin.  The same launch sums the unary terms that sweep left in
+// d_chain_unary into the slot they belong to (swept_slot), if any.
 static int chain_pairwise_enqueue(admm_ctx *c, double *slot) {
+  Reduce2Args a{};
   const int n = 2 * c->d.batch * (c->st.nrows + c->st.ncols);  // one term per half chain
-  hipLaunchKernelGGL(linear_reduce_kernel, dim3(1), dim3(256), 0, c->stream, slot + 1, c->d_chain_lin, n, 1, 0);
+  a.dst[0] = slot + 1; a.part[0] = c->d_chain_lin; a.n[0] = n;
+  int jobs = 1;
+  if (c->swept_slot) {
+    a.dst[1] = c->d_obj_slots + 2 * (size_t)c->swept_slot; a.part[1] = c->d_chain_unary; a.n[1] = n;
+    c->swept_slot = 0;
+    jobs = 2;
+  }
+  hipLaunchKernelGGL(linear_reduce2_kernel, dim3(jobs), dim3(1024), 0, c->stream, a);
   HIP_TRY(c, hipGetLastError());
   return ADMM_OK;
 }
 
-// slot[0] = unary term of the labels the last sweep started from (it left
-// them per chain in d_chain_unary).
-static int chain_unary_from_sweep(admm_ctx *c, double *slot) {
-  const int n = 2 * c->d.batch * (c->st.nrows + c->st.ncols);  // one term per half chain
-  hipLaunchKernelGGL(linear_reduce_kernel, dim3(1), dim3(256), 0, c->stream, slot, c->d_chain_unary, n, 1, 0);
+// Sums the unary terms the last sweep left in d_chain_unary into their slot now.
+static int settle_swept(admm_ctx *c) {
+  if (!c->swept_slot) return ADMM_OK;
+  Reduce2Args a{};
+  a.dst[0] = c->d_obj_slots + 2 * (size_t)c->swept_slot; a.part[0] = c->d_chain_unary;
+  a.n[0] = 2 * c->d.batch * (c->st.nrows + c->st.ncols);
+  c->swept_slot = 0;
+  hipLaunchKernelGGL(linear_reduce2_kernel, dim3(1), dim3(1024), 0, c->stream, a);
   HIP_TRY(c, hipGetLastError());
   return ADMM_OK;
 }
@@ -1093,7 +1139,13 @@ static int chain_unary_gather(admm_ctx *c, double *slot) {
 
 // Completes the queued objective that still waits for its unary term.  Must
 // run before anything changes the labels or the unaries.
+static int flush_gather(admm_ctx *c);
 static int flush_pending(admm_ctx *c) {
+  int rc = settle_swept(c);
+  if (rc) return rc;
+  return flush_gather(c);
+}
+static int flush_gather(admm_ctx *c) {
   if (!c->pending_slot) return ADMM_OK;
   const int slot = c->pending_slot;
   c->pending_slot = 0;
@@ -1157,7 +1209,7 @@ int admm_objective_enqueue(admm_ctx *c, int slot) {
   if (!is_chain(c)) return fail(c, ADMM_E_STATE, "queued objectives are a chain-solver feature");
   if (slot < 1 || slot >= c->n_obj_slots) return fail(c, ADMM_E_ARG, "slot must be in [1, %d)", c->n_obj_slots);
   if (!c->lin_valid) return fail(c, ADMM_E_STATE, "admm_objective_enqueue needs a preceding admm_compute");
-  if ((rc = flush_pending(c))) return rc;  // two requests for the same solve
+  if ((rc = flush_gather(c))) return rc;  // two requests for the same solve
   if ((rc = chain_pairwise_enqueue(c, c->d_obj_slots + 2 * (size_t)slot))) return rc;
   c->pending_slot = slot;  // the next sweep (or a read before it) supplies the unary term
   return ADMM_OK;
@@ -1168,6 +1220,7 @@ int admm_objective_read(admm_ctx *c, int slot, int n, double *linear) {
   if (rc) return rc;
   if (!is_chain(c)) return fail(c, ADMM_E_STATE, "queued objectives are a chain-solver feature");
   if (slot < 1 || n < 0 || slot + n > c->n_obj_slots) return fail(c, ADMM_E_ARG, "slot range out of bounds");
+  if (c->swept_slot >= slot && c->swept_slot < slot + n && (rc = settle_swept(c))) return rc;
   if (c->pending_slot >= slot && c->pending_slot < slot + n && (rc = flush_pending(c))) return rc;
   std::vector<double> h(2 * (size_t)n);
   HIP_TRY(c, hipMemcpyAsync(h.data(), c->d_obj_slots + 2 * (size_t)slot, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
