@@ -48,6 +48,18 @@ struct admm_ctx {
   int n_partial = 0;
   double *d_obj_slots = nullptr;  // [n_obj_slots][2] (primal, linear) queued objective values
   int n_obj_slots = 0;
+  // edge solver on several ranks (EDGE partition, Grid.cpp:445-454): V and E
+  // above are this rank's vertices and edges, vertices renumbered 0..V-1 in
+  // ascending global order (vSelfMapG2L)
+  int Vglobal = 0, Eglobal = 0, e0 = 0;
+  std::vector<int> h_lverts;         // global id per local vertex
+  std::vector<int> h_cnt;            // global copy count per local vertex (vertCnt after Grid.cpp:309-319)
+  std::vector<int> nb_rank, nb_off;  // neighbouring ranks, ascending, and where each one's shared block starts (+ end)
+  std::vector<int> h_send_idx;       // local vertex per shared entry, neighbour-major (outNeighborMapEdge)
+  std::vector<int> h_nb_cnt;         // the neighbour's own copy count per shared entry
+  std::vector<float> h_unary_local;  // unaries of the local vertices, kept for admm_init
+  int *d_cnt = nullptr, *d_send_idx = nullptr, *d_rcv_off = nullptr, *d_rcv_pos = nullptr;
+  float *d_m_part = nullptr, *d_sendv = nullptr, *d_recvv = nullptr;
 
   // ---- chain solver ----
   Strip st;
@@ -322,6 +334,69 @@ int transpose_labels2(admm_ctx *c, int *out0, const int *in0, int nr0, int nc0, 
 
 // ------------------------------------------------------------------ edge helpers
 
+// EDGE partition on several ranks.  On entry h_edges / V / E describe the whole
+// graph; on exit they describe this rank's slice (Grid.cpp:446-454) with its
+// vertices renumbered in ascending global order (GetVerts, Grid.cpp:815-856),
+// and the neighbour plan of InitNeighborsByEdge (Grid.cpp:198-331) is in place.
+// Every rank holds the whole edge list, so the plan needs no communication.
+void edge_partition(admm_ctx *c) {
+  const int P = c->d.nranks, me = c->d.rank, E = c->Eglobal;
+  auto slice = [&](int r, int *off, int *n) { admm_partition(E, P, r, off, n); };  // same split as Grid.cpp:446-454
+  // sorted distinct vertices of a rank's slice with their local copy counts
+  auto verts_of = [&](int r, std::vector<int> &vs, std::vector<int> &cn) {
+    int off, n;
+    slice(r, &off, &n);
+    std::vector<int> v(c->h_edges.begin() + 2 * (size_t)off, c->h_edges.begin() + 2 * ((size_t)off + n));
+    std::sort(v.begin(), v.end());
+    vs.clear(); cn.clear();
+    for (int x : v) {
+      if (!vs.empty() && vs.back() == x) cn.back()++;
+      else { vs.push_back(x); cn.push_back(1); }
+    }
+  };
+  std::vector<int> mine, mycnt;
+  verts_of(me, mine, mycnt);
+  c->h_lverts = mine;
+  c->h_cnt = mycnt;
+  c->nb_rank.clear(); c->nb_off.assign(1, 0); c->h_send_idx.clear(); c->h_nb_cnt.clear();
+  if (!mine.empty()) {
+    for (int r = 0; r < P; r++) {
+      if (r == me) continue;
+      int off, n;
+      slice(r, &off, &n);
+      if (n == 0) continue;
+      // a neighbour is a rank whose vertex range overlaps mine (Grid.cpp:240-251)
+      int lo = c->h_edges[2 * (size_t)off], hi = lo;
+      for (size_t i = 2 * (size_t)off; i < 2 * ((size_t)off + n); i++) { lo = std::min(lo, c->h_edges[i]); hi = std::max(hi, c->h_edges[i]); }
+      if (lo > mine.back() || mine.front() > hi) continue;
+      std::vector<int> theirs, theircnt;
+      verts_of(r, theirs, theircnt);
+      // shared vertices, ascending (Grid.cpp:264-279), and the copies the neighbour holds (Grid.cpp:288-319)
+      size_t a = 0, b = 0;
+      while (a < mine.size() && b < theirs.size()) {
+        if (mine[a] == theirs[b]) {
+          c->h_send_idx.push_back((int)a);
+          c->h_nb_cnt.push_back(theircnt[b]);
+          c->h_cnt[a] += theircnt[b];
+          a++; b++;
+        } else if (mine[a] < theirs[b]) a++; else b++;
+      }
+      c->nb_rank.push_back(r);
+      c->nb_off.push_back((int)c->h_send_idx.size());
+    }
+  }
+  // my edges with local vertex ids
+  int off, n;
+  slice(me, &off, &n);
+  std::vector<int> local(std::max(1, 2 * n));
+  for (int i = 0; i < 2 * n; i++)
+    local[i] = (int)(std::lower_bound(mine.begin(), mine.end(), c->h_edges[2 * (size_t)off + i]) - mine.begin());
+  c->h_edges.swap(local);
+  c->e0 = off;
+  c->E = n;
+  c->V = (int)mine.size();
+}
+
 void build_incidence(admm_ctx *c) {
   // Copies of every vertex in edge-list order: GetVerts' count (Grid.cpp:815-856)
   // plus where the copies are, so the consensus can add them in that order.
@@ -442,7 +517,6 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
     if (d.exchange != ADMM_EXCHANGE_LABELS && d.exchange != ADMM_EXCHANGE_DENSE)
       return fail(nullptr, ADMM_E_ARG, "unknown exchange mode %d", d.exchange);
   } else {
-    if (d.nranks != 1) return fail(nullptr, ADMM_E_ARG, "the edge solver runs on one strip (nranks == 1)");
     if (d.batch != 1) return fail(nullptr, ADMM_E_ARG, "the edge solver takes batch == 1");
     if (!(d.penalty_prime > 0.f)) return fail(nullptr, ADMM_E_ARG, "penalty_prime must be positive");
     if (graph && (d.num_vertices < 1 || d.num_edges < 0)) return fail(nullptr, ADMM_E_ARG, "bad graph sizes");
@@ -481,6 +555,8 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
       c->h_edges.resize(std::max(1, 2 * c->E));
       admm_grid_edges(d.rows, d.cols, c->h_edges.data());
     }
+    c->Vglobal = c->V; c->Eglobal = c->E;
+    if (d.nranks > 1) edge_partition(c);  // my slice of the edges, my vertices, my neighbours
     build_incidence(c);
     const size_t E = c->E, V = c->V, k = d.k, k2 = k * k;
     if ((rc = dev_alloc(c, &c->d_edges, 2 * E)) || (rc = dev_alloc(c, &c->d_inc_off, V + 1)) ||
@@ -489,6 +565,25 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
         (rc = dev_alloc(c, &c->d_lam_node, E * 2 * k)) || (rc = dev_alloc(c, &c->d_mu_edge, E * k2)) ||
         (rc = dev_alloc(c, &c->d_pot_edge, E * k2)) || (rc = dev_alloc(c, &c->d_m_vert, V * k)))
       return bail(rc);
+    if (d.nranks > 1) {
+      const size_t S = c->h_send_idx.size();
+      // per vertex, its entries of the receive buffer in ascending (= neighbour) order
+      std::vector<int> rcv_off(V + 1, 0), rcv_pos(std::max<size_t>(S, 1), 0);
+      for (int v : c->h_send_idx) rcv_off[v + 1]++;
+      for (size_t v = 0; v < V; v++) rcv_off[v + 1] += rcv_off[v];
+      std::vector<int> fillp(rcv_off.begin(), rcv_off.end() - 1);
+      for (size_t p = 0; p < S; p++) rcv_pos[fillp[c->h_send_idx[p]]++] = (int)p;
+      if ((rc = dev_alloc(c, &c->d_cnt, V)) || (rc = dev_alloc(c, &c->d_send_idx, S)) ||
+          (rc = dev_alloc(c, &c->d_rcv_off, V + 1)) || (rc = dev_alloc(c, &c->d_rcv_pos, S)) ||
+          (rc = dev_alloc(c, &c->d_m_part, V * k)) || (rc = dev_alloc(c, &c->d_sendv, S * k)) ||
+          (rc = dev_alloc(c, &c->d_recvv, S * k)))
+        return bail(rc);
+      hipError_t f1 = hipMemcpy(c->d_cnt, c->h_cnt.data(), sizeof(int) * V, hipMemcpyHostToDevice);
+      hipError_t f2 = S ? hipMemcpy(c->d_send_idx, c->h_send_idx.data(), sizeof(int) * S, hipMemcpyHostToDevice) : hipSuccess;
+      hipError_t f3 = hipMemcpy(c->d_rcv_off, rcv_off.data(), sizeof(int) * (V + 1), hipMemcpyHostToDevice);
+      hipError_t f4 = S ? hipMemcpy(c->d_rcv_pos, rcv_pos.data(), sizeof(int) * S, hipMemcpyHostToDevice) : hipSuccess;
+      if (f1 != hipSuccess || f2 != hipSuccess || f3 != hipSuccess || f4 != hipSuccess) { c->err = "copy of the exchange plan failed"; return bail(ADMM_E_HIP); }
+    }
     c->n_partial = 1024;
     if ((rc = dev_alloc(c, &c->d_partial, (size_t)c->n_partial))) return bail(rc);
     hipError_t e1 = hipMemcpy(c->d_edges, c->h_edges.data(), sizeof(int) * 2 * E, hipMemcpyHostToDevice);
@@ -567,6 +662,20 @@ int admm_destroy(admm_ctx *c) {
   return ADMM_OK;
 }
 
+int admm_edge_local_info(const admm_ctx *c, int *edge0, int *nedges, int *nverts) {
+  if (!c || is_chain(c)) return ADMM_E_ARG;
+  if (edge0) *edge0 = c->e0;
+  if (nedges) *nedges = c->E;
+  if (nverts) *nverts = c->V;
+  return ADMM_OK;
+}
+
+int admm_edge_local_vertices(const admm_ctx *c, int32_t *ids) {
+  if (!c || is_chain(c) || !ids) return ADMM_E_ARG;
+  for (int v = 0; v < c->V; v++) ids[v] = c->d.nranks > 1 ? c->h_lverts[v] : v;
+  return ADMM_OK;
+}
+
 int admm_strip_info(const admm_ctx *c, int *row0, int *nrows, int *col0, int *ncols) {
   if (!c) return ADMM_E_ARG;
   if (row0) *row0 = c->st.row0;
@@ -583,6 +692,13 @@ int admm_upload_unaries(admm_ctx *c, const float *unary) {
   if ((rc = flush_pending(c))) return rc;  // a queued objective still needs the old unaries
   const size_t k = c->d.k;
   if (!is_chain(c)) {
+    if (c->d.nranks > 1) {
+      // this rank's vertices, in its own numbering; kept on the host for admm_init
+      c->h_unary_local.resize((size_t)c->V * k);
+      for (int v = 0; v < c->V; v++)
+        memcpy(c->h_unary_local.data() + (size_t)v * k, unary + (size_t)c->h_lverts[v] * k, sizeof(float) * k);
+      unary = c->h_unary_local.data();
+    }
     HIP_TRY(c, hipMemcpyAsync(c->d_vert_pot, unary, sizeof(float) * (size_t)c->V * k, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   } else {
@@ -621,7 +737,8 @@ int admm_upload_pairwise(admm_ctx *c, const float *table, int per_edge) {
       if ((rc = dev_alloc(c, &c->d_edge_pot, n))) return rc;
     }
     c->pair_per_edge = per_edge ? 1 : 0;
-    HIP_TRY(c, hipMemcpy(c->d_edge_pot, table, sizeof(float) * n, hipMemcpyHostToDevice));
+    // a per-edge table covers the whole graph: take this rank's edges
+    HIP_TRY(c, hipMemcpy(c->d_edge_pot, table + (per_edge ? k2 * (size_t)c->e0 : 0), sizeof(float) * n, hipMemcpyHostToDevice));
   }
   c->have_pair = true;
   c->inited = false;
@@ -668,6 +785,44 @@ int admm_init(admm_ctx *c) {
     if (E > 0) {
       hipLaunchKernelGGL(edge_init_node_kernel, dim3(grid_for(E * 2 * k, 256)), dim3(256), 0, s, c->d_pot_node,
                          c->d_mu_node, c->d_lam_node, c->d_vert_pot, c->d_edges, c->d_inc_off, (int)E, (int)k, d.rho, c->inv_k);
+      if (d.nranks > 1) {
+        // Grid.cpp:1478-1487 across ranks: my copies of theta_v added one by
+        // one, then every neighbour's sum (its copies added one by one) in
+        // ascending rank order, divided by the global count; then InitTree
+        // (Grid.cpp:952-956).  All operands are known here, so the exchange of
+        // Grid.cpp:1486 is evaluated locally.  This overwrites what the
+        // kernel above wrote into pot_node with single-rank counts.
+        std::vector<float> avg((size_t)V * k);
+        std::vector<int> own(c->V, 0);
+        for (long long i = 0; i < 2 * E; i++) own[c->h_edges[i]]++;
+        for (long long v = 0; v < V; v++)
+          for (long long l = 0; l < k; l++) {
+            const float th = c->h_unary_local[v * k + l];
+            float sum = 0.0f;
+            for (int q = 0; q < own[v]; q++) sum += th;
+            avg[v * k + l] = sum;
+          }
+        for (size_t p = 0; p < c->h_send_idx.size(); p++) {  // neighbour-major = ascending rank
+          const long long v = c->h_send_idx[p];
+          for (long long l = 0; l < k; l++) {
+            const float th = c->h_unary_local[v * k + l];
+            float part = 0.0f;
+            for (int q = 0; q < c->h_nb_cnt[p]; q++) part += th;
+            avg[v * k + l] += part;
+          }
+        }
+        std::vector<float> pot((size_t)E * 2 * k);
+        for (long long i = 0; i < 2 * E; i++) {
+          const long long v = c->h_edges[i];
+          for (long long l = 0; l < k; l++) {
+            float a = avg[v * k + l];
+            a /= c->h_cnt[v];
+            pot[i * k + l] = a / (d.rho * c->h_cnt[v]);
+          }
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->d_pot_node, pot.data(), sizeof(float) * pot.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+      }
       hipLaunchKernelGGL(edge_init_edge_kernel, dim3(grid_for(E * k2, 256)), dim3(256), 0, s, c->d_pot_edge,
                          c->d_mu_edge, c->d_edge_pot, c->pair_per_edge, E * k2, (int)k2, d.rho, inv_k2);
     }
@@ -825,6 +980,20 @@ int unpack_received(admm_ctx *c) {
 
 }  // namespace
 
+// Edge solver on several ranks: this rank's partial consensus sums, and the
+// ones it shares packed neighbour by neighbour (Grid.cpp:1645-1651).
+static int edge_pack_partials(admm_ctx *c) {
+  const long long n = (long long)c->V * c->d.k;
+  hipLaunchKernelGGL(edge_partial_kernel, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d_m_part, c->d_mu_node,
+                     c->d_inc_off, c->d_inc, c->V, c->d.k);
+  const int S = (int)c->h_send_idx.size();
+  if (S > 0)
+    hipLaunchKernelGGL(edge_pack_kernel, dim3(grid_for((long long)S * c->d.k, 256)), dim3(256), 0, c->stream, c->d_sendv,
+                       c->d_m_part, c->d_send_idx, S, c->d.k);
+  HIP_TRY(c, hipGetLastError());
+  return ADMM_OK;
+}
+
 int admm_communicate(admm_ctx *c) {
   int rc = check_ctx(c);
   if (rc) return rc;
@@ -832,6 +1001,19 @@ int admm_communicate(admm_ctx *c) {
   const admm_desc &d = c->d;
   if (d.nranks == 1) return ADMM_OK;  // no neighbours: Grid.cpp:1643 loops zero times
   if (!c->comm) return fail(c, ADMM_E_COMM, "admm_comm_init must be called before admm_communicate when nranks > 1");
+  if (!is_chain(c)) {
+    // CommunicateByEdge (Grid.cpp:1639-1663): one message to and one from every neighbour
+    if ((rc = edge_pack_partials(c))) return rc;
+    NCCL_TRY(c, ncclGroupStart());
+    for (size_t q = 0; q < c->nb_rank.size(); q++) {
+      const size_t off = (size_t)c->nb_off[q] * d.k, n = (size_t)(c->nb_off[q + 1] - c->nb_off[q]) * d.k;
+      if (n == 0) continue;
+      NCCL_TRY(c, ncclSend(c->d_sendv + off, n, ncclFloat, c->nb_rank[q], c->comm, c->stream));
+      NCCL_TRY(c, ncclRecv(c->d_recvv + off, n, ncclFloat, c->nb_rank[q], c->comm, c->stream));
+    }
+    NCCL_TRY(c, ncclGroupEnd());
+    return ADMM_OK;
+  }
   hipStream_t s = c->stream;
   const int G = d.nranks;
   const int nr = c->st.nrows, nc = c->st.ncols;
@@ -856,7 +1038,19 @@ int admm_communicate(admm_ctx *c) {
 
 int admm_exchange_counts(admm_ctx *c, int64_t *send_counts, int64_t *recv_counts) {
   if (!c) return ADMM_E_ARG;
-  if (!is_chain(c)) return fail(c, ADMM_E_STATE, "the label exchange belongs to the chain solver");
+  if (!is_chain(c)) {
+    // edge solver: k floats per shared vertex to and from every neighbouring rank
+    for (int h = 0; h < c->d.nranks; h++) {
+      if (send_counts) send_counts[h] = 0;
+      if (recv_counts) recv_counts[h] = 0;
+    }
+    for (size_t q = 0; q < c->nb_rank.size(); q++) {
+      const int64_t n = (int64_t)(c->nb_off[q + 1] - c->nb_off[q]) * c->d.k;
+      if (send_counts) send_counts[c->nb_rank[q]] = n;
+      if (recv_counts) recv_counts[c->nb_rank[q]] = n;
+    }
+    return ADMM_OK;
+  }
   const ExchangePlan p = make_plan(c);
   for (int h = 0; h < c->d.nranks; h++) {
     const int64_t m = c->d.exchange == ADMM_EXCHANGE_DENSE ? c->d.k : 1;
@@ -869,10 +1063,17 @@ int admm_exchange_counts(admm_ctx *c, int64_t *send_counts, int64_t *recv_counts
 int admm_exchange_pack_host(admm_ctx *c, int32_t *host_send) {
   int rc = check_ctx(c);
   if (rc) return rc;
-  if (!is_chain(c)) return fail(c, ADMM_E_STATE, "the label exchange belongs to the chain solver");
   if (!c->inited) return fail(c, ADMM_E_STATE, "exchange before admm_init");
   if (!host_send) return fail(c, ADMM_E_ARG, "null buffer");
   if (c->d.nranks == 1) return ADMM_OK;
+  if (!is_chain(c)) {
+    // the neighbours are in ascending rank order, so the packed buffer is peer-major as it stands
+    if ((rc = edge_pack_partials(c))) return rc;
+    const size_t n = c->h_send_idx.size() * (size_t)c->d.k;
+    if (n) HIP_TRY(c, hipMemcpyAsync(host_send, c->d_sendv, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ADMM_OK;
+  }
   const ExchangePlan p = make_plan(c);
   if ((rc = pack_labels(c, p))) return rc;
   const int G = c->d.nranks;
@@ -894,10 +1095,15 @@ int admm_exchange_pack_host(admm_ctx *c, int32_t *host_send) {
 int admm_exchange_unpack_host(admm_ctx *c, const int32_t *host_recv) {
   int rc = check_ctx(c);
   if (rc) return rc;
-  if (!is_chain(c)) return fail(c, ADMM_E_STATE, "the label exchange belongs to the chain solver");
   if (!c->inited) return fail(c, ADMM_E_STATE, "exchange before admm_init");
   if (!host_recv) return fail(c, ADMM_E_ARG, "null buffer");
   if (c->d.nranks == 1) return ADMM_OK;
+  if (!is_chain(c)) {
+    const size_t n = c->h_send_idx.size() * (size_t)c->d.k;
+    if (n) HIP_TRY(c, hipMemcpyAsync(c->d_recvv, host_recv, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ADMM_OK;
+  }
   const ExchangePlan p = make_plan(c);
   const int nr = c->st.nrows, nc = c->st.ncols;
   const int32_t *src = host_recv;
@@ -920,12 +1126,49 @@ int admm_communicate_group(admm_ctx **ctxs, int n) {
   for (int g = 0; g < n; g++) {
     admm_ctx *c = ctxs[g];
     if (!c) return ADMM_E_ARG;
-    if (!is_chain(c) || c->d.nranks != n || c->d.rank != g || c->d.rows != ctxs[0]->d.rows ||
-        c->d.cols != ctxs[0]->d.cols || c->d.k != ctxs[0]->d.k || c->d.exchange != ctxs[0]->d.exchange)
+    if (c->d.solver != ctxs[0]->d.solver || c->d.nranks != n || c->d.rank != g || c->d.rows != ctxs[0]->d.rows ||
+        c->d.cols != ctxs[0]->d.cols || c->d.k != ctxs[0]->d.k || c->d.exchange != ctxs[0]->d.exchange ||
+        c->Eglobal != ctxs[0]->Eglobal || c->Vglobal != ctxs[0]->Vglobal)
       return fail(c, ADMM_E_ARG, "admm_communicate_group needs the n strips of one problem, in rank order");
     if (!c->inited) return fail(c, ADMM_E_STATE, "admm_communicate_group before admm_init");
   }
   if (n == 1) return ADMM_OK;
+  if (!is_chain(ctxs[0])) {
+    // edge solver: every rank packs, then pulls each neighbour's block for it
+    int rc;
+    for (int g = 0; g < n; g++) {
+      admm_ctx *c = ctxs[g];
+      if ((rc = check_ctx(c)) || (rc = edge_pack_partials(c))) return rc;
+      if (!c->ev_packed) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
+      if (!c->ev_pulled) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_pulled, hipEventDisableTiming));
+      HIP_TRY(c, hipEventRecord(c->ev_packed, c->stream));
+    }
+    for (int g = 0; g < n; g++) {
+      admm_ctx *r = ctxs[g];
+      if ((rc = check_ctx(r))) return rc;
+      for (size_t q = 0; q < r->nb_rank.size(); q++) {
+        admm_ctx *sd = ctxs[r->nb_rank[q]];
+        // my block in the neighbour's send buffer: where it lists me
+        size_t qq = 0;
+        while (qq < sd->nb_rank.size() && sd->nb_rank[qq] != g) qq++;
+        const size_t cnt = (size_t)(r->nb_off[q + 1] - r->nb_off[q]);
+        if (qq == sd->nb_rank.size() || (size_t)(sd->nb_off[qq + 1] - sd->nb_off[qq]) != cnt)
+          return fail(r, ADMM_E_STATE, "the exchange plans of ranks %d and %d disagree", g, r->nb_rank[q]);
+        HIP_TRY(r, hipStreamWaitEvent(r->stream, sd->ev_packed, 0));
+        if (cnt)
+          HIP_TRY(r, hipMemcpyPeerAsync(r->d_recvv + (size_t)r->nb_off[q] * r->d.k, r->d.device,
+                                        sd->d_sendv + (size_t)sd->nb_off[qq] * r->d.k, sd->d.device,
+                                        cnt * r->d.k * sizeof(float), r->stream));
+      }
+      HIP_TRY(r, hipEventRecord(r->ev_pulled, r->stream));
+    }
+    for (int g = 0; g < n; g++) {
+      admm_ctx *c = ctxs[g];
+      if ((rc = check_ctx(c))) return rc;
+      for (int h : c->nb_rank) HIP_TRY(c, hipStreamWaitEvent(c->stream, ctxs[h]->ev_pulled, 0));
+    }
+    return ADMM_OK;
+  }
   std::vector<ExchangePlan> plans;
   int rc;
   // 1. every strip packs on its own stream and marks the point
@@ -974,8 +1217,12 @@ int admm_update(admm_ctx *c) {
   const admm_desc &d = c->d;
   if (!is_chain(c)) {
     const long long n = (long long)c->V * d.k;
-    hipLaunchKernelGGL(edge_consensus_kernel, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d_m_vert,
-                       c->d_mu_node, c->d_inc_off, c->d_inc, c->V, d.k);
+    if (d.nranks > 1)  // UpdateMuArrAfterComm on the sums Communicate left (Grid.cpp:163-181)
+      hipLaunchKernelGGL(edge_finalize_kernel, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d_m_vert,
+                         c->d_m_part, c->d_recvv, c->d_rcv_off, c->d_rcv_pos, c->d_cnt, c->V, d.k);
+    else
+      hipLaunchKernelGGL(edge_consensus_kernel, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d_m_vert,
+                         c->d_mu_node, c->d_inc_off, c->d_inc, c->V, d.k);
     HIP_TRY(c, hipGetLastError());
     return ADMM_OK;
   }

@@ -183,6 +183,48 @@ __global__ void edge_consensus_kernel(float *__restrict__ m_vert, const float *_
   }
 }
 
+// The same on several ranks (Grid.cpp:1639-1663, 163-181).  A rank first sums
+// its own copies of every vertex its edges touch, in edge-list order ...
+__global__ void edge_partial_kernel(float *__restrict__ m_part, const float *__restrict__ mu_node,
+                                    const int *__restrict__ inc_off, const int *__restrict__ inc,
+                                    int V, int k) {
+  const long long total = (long long)V * k;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(idx / k), l = (int)(idx % k);
+    float s = 0.0f;
+    for (int q = inc_off[v]; q < inc_off[v + 1]; q++) s += mu_node[(long long)inc[q] * k + l];
+    m_part[idx] = s;
+  }
+}
+
+// ... packs the sums of the vertices it shares with each neighbouring rank
+// (send_idx: local vertex per shared entry, neighbour-major, Grid.cpp:1648-1651) ...
+__global__ void edge_pack_kernel(float *__restrict__ sendv, const float *__restrict__ m_part,
+                                 const int *__restrict__ send_idx, int S, int k) {
+  const long long total = (long long)S * k;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x)
+    sendv[idx] = m_part[(long long)send_idx[idx / k] * k + idx % k];
+}
+
+// ... and, once the neighbours' sums have arrived (recvv, neighbour-major in
+// ascending rank order), adds them in that order and divides by the global
+// copy count.  rcv_pos lists, per vertex, its entries of recvv in ascending order.
+__global__ void edge_finalize_kernel(float *__restrict__ m_vert, const float *__restrict__ m_part,
+                                     const float *__restrict__ recvv, const int *__restrict__ rcv_off,
+                                     const int *__restrict__ rcv_pos, const int *__restrict__ cnt,
+                                     int V, int k) {
+  const long long total = (long long)V * k;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(idx / k), l = (int)(idx % k);
+    float s = m_part[idx];
+    for (int q = rcv_off[v]; q < rcv_off[v + 1]; q++) s += recvv[(long long)rcv_pos[q] * k + l];
+    m_vert[idx] = s / cnt[v];
+  }
+}
+
 // Initial split of the unaries (Grid.cpp:1478-1487, 952-956): theta_v added
 // once per copy, divided by the copy count, then by rho * count.
 __global__ void edge_init_node_kernel(float *__restrict__ pot_node, float *__restrict__ mu_node,

@@ -166,7 +166,7 @@ void Grid::InitOptimization() {
   d.rows = numGlobalRows; d.cols = numGlobalCols; d.k = numVertPotentials; d.batch = batch;
   d.solver = part == EDGE ? ADMM_SOLVER_EDGE_BETHE : ADMM_SOLVER_CHAIN_MINSUM;
   d.penalty = penalty; d.penalty_prime = penaltyPrime; d.rho = rhoEdge;
-  d.device = device; d.rank = part == EDGE ? 0 : rank; d.nranks = part == EDGE ? 1 : numProcs;
+  d.device = device; d.rank = rank; d.nranks = numProcs;
   d.exchange = ADMM_EXCHANGE_LABELS;
   if (part == EDGE && fromFile) {  // any graph: hand the file's edge list over (Grid.cpp:476-494)
     d.edge_list = edgeList.data();

@@ -278,6 +278,19 @@ class Grid:
         self._ck(lib.admm_strip_info(self._h, *[C.byref(x) for x in v]))
         return tuple(x.value for x in v)
 
+    def EdgeLocalInfo(self):
+        """Edge solver: (first edge, number of edges, number of distinct vertices) of this rank."""
+        v = [C.c_int() for _ in range(3)]
+        self._ck(lib.admm_edge_local_info(self._h, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
+    def EdgeLocalVertices(self):
+        """Edge solver: global ids of this rank's vertices, ascending (the rows of Consensus())."""
+        n = self.EdgeLocalInfo()[2]
+        out = np.empty(max(n, 1), dtype=np.int32)
+        self._ck(lib.admm_edge_local_vertices(self._h, out.ctypes.data_as(_ip)))
+        return out[:n]
+
     def Labels(self):
         _, nrows, _, _ = self.StripInfo()
         out = np.empty((self.batch, nrows, self.cols), dtype=np.int32)
@@ -286,8 +299,10 @@ class Grid:
 
     def Consensus(self):
         if self.part == EDGE:
-            V = self._num_vertices if self._edge_list is not None else self.rows * self.cols
+            V = self.EdgeLocalInfo()[2]
             out = np.empty((V, self.k), dtype=np.float32)
+            if V == 0:
+                return out
         else:
             _, nrows, _, _ = self.StripInfo()
             out = np.empty((self.batch * nrows * self.cols, self.k), dtype=np.float32)

@@ -63,7 +63,10 @@ typedef struct admm_desc {
   float rho;             /* rhoEdge, always 1.0 in the reference              */
   int32_t device;        /* HIP device ordinal                                */
   int32_t rank;          /* this context's strip, 0 <= rank < nranks          */
-  int32_t nranks;        /* strips; > 1 needs the chain solver and batch == 1 */
+  int32_t nranks;        /* strips (ranks); > 1 needs batch == 1.  Chain
+                          * solver: row / column strips.  Edge solver: the
+                          * reference's EDGE partition, contiguous slices of
+                          * the edge list (Grid.cpp:445-454)                 */
   int32_t exchange;      /* ADMM_EXCHANGE_*                                   */
   /* Edge solver on an arbitrary graph (the reference accepts any edge list,
    * Grid.cpp:476-494).  NULL: the grid's own edge list in the order of
@@ -98,8 +101,13 @@ int admm_init(admm_ctx *ctx);
  * subproblem of every tree (Tree.cpp:64-274). */
 int admm_compute(admm_ctx *ctx);
 /* Grid::Communicate (Grid.cpp:1509-1526, 1639-1663).  One strip: nothing to
- * exchange.  Several strips: RCCL all-to-all (grouped send / receive) of the
- * chain labels, or of their marginals with ADMM_EXCHANGE_DENSE. */
+ * exchange.  Several strips, chain solver: RCCL all-to-all (grouped send /
+ * receive) of the chain labels, or of their marginals with
+ * ADMM_EXCHANGE_DENSE.  Several ranks, edge solver: CommunicateByEdge, every
+ * rank sends each neighbouring rank its partial consensus sums of the vertices
+ * they share (grouped RCCL send / receive); admm_update then adds what arrived
+ * in ascending order of the neighbours' ranks, as Grid.cpp:163-173 does, so it
+ * must follow an admm_communicate. */
 int admm_communicate(admm_ctx *ctx);
 /* The same exchange when all n strips of a problem live in this process (one
  * context per strip, rank order, on one GPU or on several): device-to-device
@@ -111,7 +119,8 @@ int admm_communicate_group(admm_ctx **ctxs, int n);
 /* The same exchange staged through host memory, for a caller that brings its
  * own transport (the reference's is MPI_Isend / MPI_Irecv on packed host
  * buffers, Grid.cpp:1648-1662).  admm_exchange_counts gives the 4-byte
- * elements (labels; k floats per label with ADMM_EXCHANGE_DENSE) sent to and
+ * elements (chain solver: labels, or k floats per label with
+ * ADMM_EXCHANGE_DENSE; edge solver: k floats per shared vertex) sent to and
  * received from every rank; admm_exchange_pack_host fills host_send,
  * peer-major, and waits for it; the caller moves block h of every rank to
  * rank h; admm_exchange_unpack_host takes the received blocks, peer-major. */
@@ -145,13 +154,15 @@ int admm_finalize(admm_ctx *ctx);
 
 /* Results.  Labels: decoded labelling of this strip's rows,
  * [batch][strip rows][cols] (chain solver).  Consensus: vertMuArr after
- * Update, [batch][strip rows * cols][k] (graph mode [V][k]). */
+ * Update, [batch][strip rows * cols][k]; edge solver: [local vertices][k],
+ * which is [V][k] on one rank. */
 int admm_download_labels(admm_ctx *ctx, int32_t *labels);
 int admm_download_consensus(admm_ctx *ctx, float *consensus);
 
 /* Solver state for parity tests.  Edge solver (members of class Edge,
- * Tree.h:26-35): 0 x_mu_node, 1 x_potential_node, 2 edge_mu_node,
- * 3 lambda_node ([E][2k]); 4 x_mu_edge, 5 x_potential_edge ([E][k*k]).
+ * Tree.h:26-35), this rank's edges: 0 x_mu_node, 1 x_potential_node,
+ * 2 edge_mu_node, 3 lambda_node ([E][2k]); 4 x_mu_edge, 5 x_potential_edge
+ * ([E][k*k]).
  * Chain solver: 10 lambda of the row chains [strip rows][cols][k],
  * 11 lambda of the column chains [rows][strip cols][k], 12 per-copy unary
  * share [strip rows][cols][k]; 13 row-chain labels [strip rows][cols],
@@ -166,6 +177,12 @@ size_t admm_state_size(const admm_ctx *ctx, int which);
 void admm_partition(int n, int nranks, int rank, int *start, int *count);
 /* This context's strips. */
 int admm_strip_info(const admm_ctx *ctx, int *row0, int *nrows, int *col0, int *ncols);
+/* Edge solver: this rank's slice of the edge list (Grid::PartitionByEdge,
+ * Grid.cpp:446-454) and the number of distinct vertices its edges touch
+ * (GetVerts, Grid.cpp:815-856); their global ids in ascending order, which is
+ * the row order of admm_download_consensus (vSelfVec). */
+int admm_edge_local_info(const admm_ctx *ctx, int *edge0, int *nedges, int *nverts);
+int admm_edge_local_vertices(const admm_ctx *ctx, int32_t *ids);
 
 /* Multi-GPU bootstrap.  Rank 0 fills a 128-byte RCCL id, the caller ships it
  * to every rank by its own means (the reference's is MPI_Init), and every

@@ -263,6 +263,250 @@ float *oracle_edge_pot_edge(oracle_edge *o) { return o->pot_edge; }
 float *oracle_edge_vertmu(oracle_edge *o) { return o->vertMu; }
 
 /* ------------------------------------------------------------------ */
+/* edge solver on P ranks (EDGE partition), simulated in one process      */
+/* ------------------------------------------------------------------ */
+/*
+ * What the reference does under mpiexec -n P: rank r owns a contiguous slice
+ * of the edge list (Grid.cpp:446-454), keeps a partial consensus sum for every
+ * vertex its edges touch (Grid.cpp:815-856), and per iteration sends every
+ * neighbouring rank its partial sums of the vertices they share
+ * (Grid.cpp:1639-1663), adds what it receives in ascending order of the
+ * neighbours' ranks and divides by the global copy count (Grid.cpp:163-181).
+ * The per-edge state lives in one oracle_edge; only the consensus arithmetic
+ * depends on the partition.
+ */
+struct oracle_edge_ranks {
+  oracle_edge *g;
+  int P;
+  int *eoff;     /* P+1: rank r owns edges [eoff[r], eoff[r+1]) */
+  int *nv;       /* distinct vertices per rank */
+  int **verts;   /* vSelfVec: sorted distinct global ids */
+  int **cnt;     /* vertCnt: local copies, plus the neighbours' after init */
+  float **vmu;   /* vertMuArr [nv][k] */
+  int *nn;       /* neighbours per rank */
+  int **nb;      /* their ranks, ascending (Grid.cpp:237-252) */
+  int **ns;      /* shared vertices per neighbour */
+  int ***sh;     /* outNeighborMapEdge: shared global ids, ascending */
+  float ***recv; /* recvBuffer [neighbour][ns*k] */
+};
+
+static int cmp_int(const void *a, const void *b) {
+  int x = *(const int *)a, y = *(const int *)b;
+  return x < y ? -1 : x > y;
+}
+
+static int lvid(const oracle_edge_ranks *o, int r, int gv) { /* vSelfMapG2L */
+  int lo = 0, hi = o->nv[r] - 1;
+  while (lo <= hi) {
+    int mid = (lo + hi) / 2;
+    if (o->verts[r][mid] == gv) return mid;
+    if (o->verts[r][mid] < gv) lo = mid + 1; else hi = mid - 1;
+  }
+  return -1;
+}
+
+oracle_edge_ranks *oracle_edge_ranks_create(int V, int E, int k, const int *edgeList,
+                                            const float *vertPot, const float *edgePot,
+                                            float penalty, float penaltyPrime, float rho, int P) {
+  oracle_edge_ranks *o = (oracle_edge_ranks *)calloc(1, sizeof(*o));
+  o->g = oracle_edge_create(V, E, k, edgeList, vertPot, edgePot, penalty, penaltyPrime, rho);
+  o->P = P;
+  o->eoff = (int *)calloc((size_t)P + 1, sizeof(int));
+  for (int r = 0; r < P; r++) { /* Grid.cpp:446-454 */
+    int n = E / P, div = E % P, off;
+    if (r < div) { n += 1; off = n * r; } else { off = (n + 1) * div + n * (r - div); }
+    o->eoff[r] = off;
+    o->eoff[r + 1] = off + n;
+  }
+  o->nv = (int *)calloc((size_t)P, sizeof(int));
+  o->verts = (int **)calloc((size_t)P, sizeof(int *));
+  o->cnt = (int **)calloc((size_t)P, sizeof(int *));
+  o->vmu = (float **)calloc((size_t)P, sizeof(float *));
+  for (int r = 0; r < P; r++) { /* GetVerts, Grid.cpp:815-856 */
+    int n2 = 2 * (o->eoff[r + 1] - o->eoff[r]);
+    int *v = (int *)malloc(sizeof(int) * (size_t)(n2 > 0 ? n2 : 1));
+    memcpy(v, edgeList + 2 * (size_t)o->eoff[r], sizeof(int) * (size_t)n2);
+    qsort(v, (size_t)n2, sizeof(int), cmp_int);
+    o->verts[r] = (int *)malloc(sizeof(int) * (size_t)(n2 > 0 ? n2 : 1));
+    o->cnt[r] = (int *)calloc((size_t)(n2 > 0 ? n2 : 1), sizeof(int));
+    int nv = 0;
+    for (int i = 0; i < n2; i++) {
+      if (nv > 0 && o->verts[r][nv - 1] == v[i]) o->cnt[r][nv - 1]++;
+      else { o->verts[r][nv] = v[i]; o->cnt[r][nv] = 1; nv++; }
+    }
+    o->nv[r] = nv;
+    o->vmu[r] = falloc((long long)nv * k);
+    free(v);
+  }
+  /* InitNeighborsByEdge, Grid.cpp:198-331 */
+  o->nn = (int *)calloc((size_t)P, sizeof(int));
+  o->nb = (int **)calloc((size_t)P, sizeof(int *));
+  o->ns = (int **)calloc((size_t)P, sizeof(int *));
+  o->sh = (int ***)calloc((size_t)P, sizeof(int **));
+  o->recv = (float ***)calloc((size_t)P, sizeof(float **));
+  for (int r = 0; r < P; r++) {
+    o->nb[r] = (int *)calloc((size_t)P, sizeof(int));
+    o->ns[r] = (int *)calloc((size_t)P, sizeof(int));
+    o->sh[r] = (int **)calloc((size_t)P, sizeof(int *));
+    o->recv[r] = (float **)calloc((size_t)P, sizeof(float *));
+    if (o->nv[r] == 0) continue;
+    const int lo = o->verts[r][0], hi = o->verts[r][o->nv[r] - 1];
+    for (int i = 0; i < P; i++) {
+      if (i == r || o->nv[i] == 0) continue;
+      /* neighbours are the ranks whose vertex range overlaps mine (Grid.cpp:240-251) */
+      if (o->verts[i][0] > hi || lo > o->verts[i][o->nv[i] - 1]) continue;
+      const int q = o->nn[r]++;
+      o->nb[r][q] = i;
+      /* shared vertices: the runs of both sides intersected, ascending (Grid.cpp:264-279) */
+      o->sh[r][q] = (int *)malloc(sizeof(int) * (size_t)o->nv[r]);
+      int n = 0, a = 0, b = 0;
+      while (a < o->nv[r] && b < o->nv[i]) {
+        if (o->verts[r][a] == o->verts[i][b]) { o->sh[r][q][n++] = o->verts[r][a]; a++; b++; }
+        else if (o->verts[r][a] < o->verts[i][b]) a++; else b++;
+      }
+      o->ns[r][q] = n;
+      o->recv[r][q] = falloc((long long)n * k);
+    }
+  }
+  /* global copy counts: mine plus what every neighbour reports (Grid.cpp:288-319);
+   * the reports are the neighbours' LOCAL counts, so take them before any is raised */
+  int **local = (int **)calloc((size_t)P, sizeof(int *));
+  for (int r = 0; r < P; r++) {
+    local[r] = (int *)malloc(sizeof(int) * (size_t)(o->nv[r] > 0 ? o->nv[r] : 1));
+    memcpy(local[r], o->cnt[r], sizeof(int) * (size_t)o->nv[r]);
+  }
+  for (int r = 0; r < P; r++)
+    for (int q = 0; q < o->nn[r]; q++)
+      for (int j = 0; j < o->ns[r][q]; j++) {
+        const int gv = o->sh[r][q][j];
+        o->cnt[r][lvid(o, r, gv)] += local[o->nb[r][q]][lvid(o, o->nb[r][q], gv)];
+      }
+  for (int r = 0; r < P; r++) free(local[r]);
+  free(local);
+  return o;
+}
+
+void oracle_edge_ranks_destroy(oracle_edge_ranks *o) {
+  if (!o) return;
+  for (int r = 0; r < o->P; r++) {
+    for (int q = 0; q < o->nn[r]; q++) { free(o->sh[r][q]); free(o->recv[r][q]); }
+    free(o->verts[r]); free(o->cnt[r]); free(o->vmu[r]); free(o->nb[r]); free(o->ns[r]);
+    free(o->sh[r]); free(o->recv[r]);
+  }
+  free(o->eoff); free(o->nv); free(o->verts); free(o->cnt); free(o->vmu); free(o->nn);
+  free(o->nb); free(o->ns); free(o->sh); free(o->recv);
+  oracle_edge_destroy(o->g);
+  free(o);
+}
+
+/* CommunicateByEdge (Grid.cpp:1639-1663) for all ranks at once, then
+ * UpdateMuArrAfterComm (Grid.cpp:163-181). */
+static void ranks_exchange_and_average(oracle_edge_ranks *o) {
+  const int k = o->g->k;
+  for (int r = 0; r < o->P; r++) /* every message leaves before any sum changes */
+    for (int q = 0; q < o->nn[r]; q++) {
+      const int i = o->nb[r][q];
+      for (int j = 0; j < o->ns[r][q]; j++)
+        memcpy(o->recv[r][q] + (size_t)j * k, o->vmu[i] + (size_t)lvid(o, i, o->sh[r][q][j]) * k,
+               sizeof(float) * (size_t)k);
+    }
+  for (int r = 0; r < o->P; r++) {
+    for (int q = 0; q < o->nn[r]; q++)
+      for (int j = 0; j < o->ns[r][q]; j++) {
+        float *dst = o->vmu[r] + (size_t)lvid(o, r, o->sh[r][q][j]) * k;
+        for (int l = 0; l < k; l++) dst[l] += o->recv[r][q][(size_t)j * k + l];
+      }
+    for (int v = 0; v < o->nv[r]; v++)
+      for (int l = 0; l < k; l++) o->vmu[r][(size_t)v * k + l] /= o->cnt[r][v];
+  }
+}
+
+void oracle_edge_ranks_init(oracle_edge_ranks *o) {
+  oracle_edge *g = o->g;
+  const int k = g->k, k2 = g->k2;
+  /* Grid.cpp:1478-1487.  The reference indexes the unaries it read (a
+   * contiguous range of vertices) by local id (Grid.cpp:510-523, 1482), which
+   * is the vertex's own row as long as a rank's vertex set has no gaps; the
+   * vertex's own row is used here. */
+  for (int r = 0; r < o->P; r++) {
+    memset(o->vmu[r], 0, sizeof(float) * (size_t)o->nv[r] * k);
+    for (int i = 2 * o->eoff[r]; i < 2 * o->eoff[r + 1]; i++) {
+      const int gv = g->edgeList[i], lv = lvid(o, r, gv);
+      for (int j = 0; j < k; j++) o->vmu[r][(size_t)lv * k + j] += g->vertPot[(size_t)gv * k + j];
+    }
+  }
+  ranks_exchange_and_average(o);
+  const float inv_k = 1.0 / (float)k;
+  const float inv_k2 = 1.0 / (float)k2;
+  for (int r = 0; r < o->P; r++)
+    for (int e = o->eoff[r]; e < o->eoff[r + 1]; e++) { /* InitTree, Grid.cpp:944-979 */
+      const int l = lvid(o, r, g->edgeList[2 * e]), rr = lvid(o, r, g->edgeList[2 * e + 1]);
+      float *pn = g->pot_node + (size_t)e * 2 * k;
+      for (int j = 0; j < k; j++) {
+        pn[j] = o->vmu[r][(size_t)l * k + j] / (g->rho * o->cnt[r][l]);
+        pn[k + j] = o->vmu[r][(size_t)rr * k + j] / (g->rho * o->cnt[r][rr]);
+      }
+      for (int j = 0; j < 2 * k; j++) {
+        g->mu_node[(size_t)e * 2 * k + j] = inv_k;
+        g->m_node[(size_t)e * 2 * k + j] = inv_k;
+        g->lambda_node[(size_t)e * 2 * k + j] = 0.0f;
+      }
+      for (int j = 0; j < k2; j++) {
+        g->pot_edge[(size_t)e * k2 + j] = g->edgePot[(size_t)e * k2 + j] / g->rho;
+        g->mu_edge[(size_t)e * k2 + j] = inv_k2;
+      }
+    }
+}
+
+void oracle_edge_ranks_compute(oracle_edge_ranks *o) {
+  oracle_edge *g = o->g;
+  const int k = g->k, k2 = g->k2;
+  for (int r = 0; r < o->P; r++) {
+    memset(o->vmu[r], 0, sizeof(float) * (size_t)o->nv[r] * k); /* Grid.cpp:144-148 */
+    for (int e = o->eoff[r]; e < o->eoff[r + 1]; e++) {         /* Grid.cpp:1400-1410 */
+      const int l = lvid(o, r, g->edgeList[2 * e]), rr = lvid(o, r, g->edgeList[2 * e + 1]);
+      oracle_edge_solve_one(k, g->mu_node + (size_t)e * 2 * k, g->pot_node + (size_t)e * 2 * k,
+                            g->m_node + (size_t)e * 2 * k, g->lambda_node + (size_t)e * 2 * k,
+                            g->mu_edge + (size_t)e * k2, g->pot_edge + (size_t)e * k2,
+                            g->penalty, g->penaltyPrime, g->rho,
+                            o->vmu[r] + (size_t)l * k, o->vmu[r] + (size_t)rr * k);
+    }
+  }
+}
+
+void oracle_edge_ranks_update(oracle_edge_ranks *o) {
+  oracle_edge *g = o->g;
+  const int k = g->k;
+  ranks_exchange_and_average(o); /* Communicate + UpdateMuArrAfterComm */
+  for (int r = 0; r < o->P; r++)
+    for (int i = 2 * o->eoff[r]; i < 2 * o->eoff[r + 1]; i++) /* Grid.cpp:188-192 */
+      memcpy(g->m_node + (size_t)(i / 2) * 2 * k + (size_t)(i % 2) * k,
+             o->vmu[r] + (size_t)lvid(o, r, g->edgeList[i]) * k, sizeof(float) * (size_t)k);
+}
+
+double oracle_edge_ranks_objective(const oracle_edge_ranks *o) {
+  const oracle_edge *g = o->g;
+  double total = 0.0; /* MPI_Reduce SUM of the ranks' values, admm.cpp:94-95 */
+  for (int r = 0; r < o->P; r++) {
+    double obj = 0.0; /* Grid.cpp:1665-1680 */
+    for (int e = o->eoff[r]; e < o->eoff[r + 1]; e++) {
+      for (int j = 0; j < 2 * g->k; j++)
+        obj += g->pot_node[(size_t)e * 2 * g->k + j] * g->mu_node[(size_t)e * 2 * g->k + j];
+      for (int j = 0; j < g->k2; j++)
+        obj += g->pot_edge[(size_t)e * g->k2 + j] * g->mu_edge[(size_t)e * g->k2 + j];
+    }
+    total += obj * g->rho;
+  }
+  return total;
+}
+
+oracle_edge *oracle_edge_ranks_state(oracle_edge_ranks *o) { return o->g; }
+int oracle_edge_ranks_nverts(const oracle_edge_ranks *o, int r) { return o->nv[r]; }
+const int *oracle_edge_ranks_verts(const oracle_edge_ranks *o, int r) { return o->verts[r]; }
+const int *oracle_edge_ranks_vertcnt(const oracle_edge_ranks *o, int r) { return o->cnt[r]; }
+float *oracle_edge_ranks_vertmu(oracle_edge_ranks *o, int r) { return o->vmu[r]; }
+
+/* ------------------------------------------------------------------ */
 /* chain solver                                                         */
 /* ------------------------------------------------------------------ */
 /*

@@ -72,6 +72,25 @@ float *oracle_edge_mu_edge(oracle_edge *o);          /* E*k*k   */
 float *oracle_edge_pot_edge(oracle_edge *o);         /* E*k*k   */
 float *oracle_edge_vertmu(oracle_edge *o);           /* V*k     */
 
+/* The same solver as the reference runs it on P MPI ranks (EDGE partition:
+ * Grid.cpp:445-454, 198-331, 1639-1663, 163-181), all ranks simulated in one
+ * process.  The per-edge state is that of an oracle_edge; only the order in
+ * which a vertex's copies are summed depends on P. */
+typedef struct oracle_edge_ranks oracle_edge_ranks;
+oracle_edge_ranks *oracle_edge_ranks_create(int V, int E, int k, const int *edgeList,
+                                            const float *vertPot, const float *edgePot,
+                                            float penalty, float penaltyPrime, float rho, int P);
+void oracle_edge_ranks_destroy(oracle_edge_ranks *o);
+void oracle_edge_ranks_init(oracle_edge_ranks *o);
+void oracle_edge_ranks_compute(oracle_edge_ranks *o);
+void oracle_edge_ranks_update(oracle_edge_ranks *o);   /* Communicate + Update */
+double oracle_edge_ranks_objective(const oracle_edge_ranks *o);
+oracle_edge *oracle_edge_ranks_state(oracle_edge_ranks *o);      /* per-edge arrays */
+int oracle_edge_ranks_nverts(const oracle_edge_ranks *o, int r);
+const int *oracle_edge_ranks_verts(const oracle_edge_ranks *o, int r);   /* sorted global ids */
+const int *oracle_edge_ranks_vertcnt(const oracle_edge_ranks *o, int r); /* global copy counts */
+float *oracle_edge_ranks_vertmu(oracle_edge_ranks *o, int r);            /* nverts*k */
+
 /* Threads used by oracle_chain_compute* (one chain per thread; default 1). */
 void oracle_set_threads(int n);
 

@@ -48,6 +48,25 @@ def _load():
         f = getattr(lib, "oracle_edge_" + n)
         f.restype = _fp
         f.argtypes = [C.c_void_p]
+    lib.oracle_edge_ranks_create.restype = C.c_void_p
+    lib.oracle_edge_ranks_create.argtypes = [C.c_int, C.c_int, C.c_int, _ip, _fp, _fp,
+                                             C.c_float, C.c_float, C.c_float, C.c_int]
+    for n in ("destroy", "init", "compute", "update"):
+        f = getattr(lib, "oracle_edge_ranks_" + n)
+        f.restype = None
+        f.argtypes = [C.c_void_p]
+    lib.oracle_edge_ranks_objective.restype = C.c_double
+    lib.oracle_edge_ranks_objective.argtypes = [C.c_void_p]
+    lib.oracle_edge_ranks_state.restype = C.c_void_p
+    lib.oracle_edge_ranks_state.argtypes = [C.c_void_p]
+    lib.oracle_edge_ranks_nverts.restype = C.c_int
+    lib.oracle_edge_ranks_nverts.argtypes = [C.c_void_p, C.c_int]
+    for n in ("verts", "vertcnt"):
+        f = getattr(lib, "oracle_edge_ranks_" + n)
+        f.restype = _ip
+        f.argtypes = [C.c_void_p, C.c_int]
+    lib.oracle_edge_ranks_vertmu.restype = _fp
+    lib.oracle_edge_ranks_vertmu.argtypes = [C.c_void_p, C.c_int]
     lib.oracle_set_threads.restype = None
     lib.oracle_set_threads.argtypes = [C.c_int]
     lib.oracle_chain_create.restype = C.c_void_p
@@ -179,6 +198,56 @@ class EdgeOracle:
             "pot_edge": self._view("pot_edge", E * k * k).copy(),
             "vertmu": self._view("vertmu", self.V * k).copy(),
         }
+
+
+class EdgeRanksOracle:
+    """The reference algorithm as it runs on P MPI ranks (EDGE partition), all
+    ranks simulated in one process."""
+
+    def __init__(self, V, edge_list, k, vert_pot, edge_pot, nranks, penalty=0.5, penalty_prime=1.0, rho=1.0):
+        self.V, self.k, self.P = int(V), int(k), int(nranks)
+        self.edge_list = np.ascontiguousarray(edge_list, dtype=np.int32)
+        self.E = self.edge_list.size // 2
+        vp = np.ascontiguousarray(vert_pot, dtype=np.float32).reshape(-1)
+        ep = np.ascontiguousarray(edge_pot, dtype=np.float32).reshape(-1)
+        assert vp.size == self.V * k and ep.size == self.E * k * k
+        self.h = lib.oracle_edge_ranks_create(self.V, self.E, k, _i(self.edge_list), _f(vp), _f(ep),
+                                              penalty, penalty_prime, rho, self.P)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.oracle_edge_ranks_destroy(self.h)
+            self.h = None
+
+    def init(self):
+        lib.oracle_edge_ranks_init(self.h)
+
+    def compute(self):
+        lib.oracle_edge_ranks_compute(self.h)
+
+    def update(self):
+        lib.oracle_edge_ranks_update(self.h)
+
+    def objective(self):
+        return lib.oracle_edge_ranks_objective(self.h)
+
+    def state(self):
+        """Per-edge arrays, in global edge order."""
+        g = lib.oracle_edge_ranks_state(self.h)
+        E, k = self.E, self.k
+        view = lambda name, n: np.ctypeslib.as_array(getattr(lib, "oracle_edge_" + name)(g), shape=(n,)).copy()
+        return {"mu_node": view("mu_node", E * 2 * k), "pot_node": view("pot_node", E * 2 * k),
+                "m_node": view("m_node", E * 2 * k), "lambda_node": view("lambda_node", E * 2 * k),
+                "mu_edge": view("mu_edge", E * k * k), "pot_edge": view("pot_edge", E * k * k)}
+
+    def rank_vertices(self, r):
+        """(sorted global ids, global copy counts, consensus [n, k]) of rank r."""
+        n = lib.oracle_edge_ranks_nverts(self.h, r)
+        if n == 0:
+            return np.empty(0, np.int32), np.empty(0, np.int32), np.empty((0, self.k), np.float32)
+        return (np.ctypeslib.as_array(lib.oracle_edge_ranks_verts(self.h, r), shape=(n,)).copy(),
+                np.ctypeslib.as_array(lib.oracle_edge_ranks_vertcnt(self.h, r), shape=(n,)).copy(),
+                np.ctypeslib.as_array(lib.oracle_edge_ranks_vertmu(self.h, r), shape=(n * self.k,)).reshape(n, self.k).copy())
 
 
 def edge_solve_one(k, mu, pot, m, lam, mue, pote, penalty=0.5, penalty_prime=1.0, rho=1.0, fn=None):

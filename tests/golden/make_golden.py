@@ -118,6 +118,10 @@ if __name__ == "__main__":
                    "it3_m_v4": [0.508847475, 0.491152525],
                    "it3_edge0_mu": [0.279582053, 0.720417976, 0.310885429, 0.689114511],
                    "it3_edge0_lambda": [-0.00725613534, 0.00725615025, -0.0130264163, 0.0130263269]},
+        "64x64_k4_2ranks": {"100": 2024.650422, "500": 2015.785286},
+        "64x64_k4_4ranks": {"100": 2024.650435, "500": 2015.785304},
+        "source_ranks": "the same run under mpiexec -n 2 and -n 4 (EDGE partition), values printed by the "
+                        "unmodified reference binary",
     }
     with open(os.path.join(HERE, "known_answers.json"), "w") as f:
         json.dump(known, f, indent=1)

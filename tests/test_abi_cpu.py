@@ -81,7 +81,7 @@ def test_create_rejects_bad_arguments_and_reports_why():
     d.k, d.solver = 4, 7
     assert lib.admm_create(C.byref(d), C.byref(h)) == -1
     assert b"solver" in lib.admm_last_error(None)
-    d.solver, d.nranks, d.rank = 0, 2, 0
+    d.solver, d.nranks, d.rank, d.batch = 0, 2, 0, 2
     assert lib.admm_create(C.byref(d), C.byref(h)) == -1
     assert b"edge solver" in lib.admm_last_error(None)
     d.solver, d.batch = 1, 3

@@ -175,3 +175,38 @@ def test_chain_oracle_against_brute_force():
                 best = (val, lab)
         got_val = sum(float(th[t, got[t]]) for t in range(T)) + sum(float(W[got[t], got[t + 1]]) for t in range(T - 1))
         assert abs(got_val - best[0]) < 1e-6
+
+
+def test_edge_ranks_oracle_one_rank_is_the_plain_oracle():
+    R, C, k = 7, 6, 3
+    un, W = O.synth_problem(R, C, k, 5, "dense")
+    el = O.grid_edges(R, C)
+    ep = np.tile(W.reshape(-1), el.size // 2)
+    a = O.EdgeOracle(R * C, el, k, un, ep)
+    b = O.EdgeRanksOracle(R * C, el, k, un, ep, 1)
+    a.init(); b.init()
+    for _ in range(10):
+        a.compute(); a.update()
+        b.compute(); b.update()
+    sa, sb = a.state(), b.state()
+    for n in sb:
+        assert np.array_equal(sa[n], sb[n]), n
+    assert a.objective() == b.objective()
+
+
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_edge_ranks_oracle_reproduces_the_reference_on_several_ranks(ranks):
+    """totalObj at iterations 100 and 500 as the unmodified reference printed it under
+    mpiexec -n 2 and -n 4: pins the partition, the neighbour plan and the order in which
+    a vertex's partial sums are added (Grid.cpp:445-454, 198-331, 163-181)."""
+    known = json.load(open(os.path.join(GOLD, "known_answers.json")))["64x64_k4_%dranks" % ranks]
+    R = C = 64
+    k = 4
+    un, W = O.synth_problem(R, C, k, 1234, "potts")
+    el = O.grid_edges(R, C)
+    o = O.EdgeRanksOracle(R * C, el, k, un, np.tile(W.reshape(-1), el.size // 2), ranks)
+    o.init()
+    for it in range(1, 501):
+        o.compute(); o.update()
+        if str(it) in known:
+            assert "%.6f" % o.objective() == "%.6f" % known[str(it)], (it, o.objective(), known[str(it)])
