@@ -131,6 +131,36 @@ __device__ __forceinline__ int first_equal(const float *c, const float best) {
   }
 }
 
+// The same with the result scaled: SC * (lowest index i with c[i] == best).
+template <int N, int SC>
+__device__ __forceinline__ int first_equal_sc(const float *c, const float best) {
+  if constexpr (N <= 4) {
+    int idx = SC * (N - 1);
+#pragma unroll
+    for (int q = N - 2; q >= 0; q--) idx = (c[q] == best) ? SC * q : idx;
+    return idx;
+  } else {
+    constexpr int H = N / 2;
+    const bool in_lo = min_of<H>(c) == best;
+    float sel[H];
+#pragma unroll
+    for (int q = 0; q < H; q++) sel[q] = in_lo ? c[q] : c[H + q];
+    return first_equal_sc<H, SC>(sel, best) | (in_lo ? 0 : SC * H);
+  }
+}
+// ... and with an offset folded into the top-level select: lo + SC * index,
+// given hi = lo + SC * N / 2 and lo a multiple of SC * N.
+template <int N, int SC>
+__device__ __forceinline__ int first_equal_sc_base(const float *c, const float best, const int lo, const int hi) {
+  static_assert(N >= 8, "the offset rides on the first halving");
+  constexpr int H = N / 2;
+  const bool in_lo = min_of<H>(c) == best;
+  float sel[H];
+#pragma unroll
+  for (int q = 0; q < H; q++) sel[q] = in_lo ? c[q] : c[H + q];
+  return first_equal_sc<H, SC>(sel, best) | (in_lo ? lo : hi);
+}
+
 // Cross-lane exchange between the NS lanes that share a target label.
 // Returns the partner's value for lane ^ d.
 template <int D>
@@ -331,17 +361,20 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // and issues the reads of its four candidates, finish() compares them.
   typedef float f4_t __attribute__((ext_vector_type(4)));
   f4_t m4_pend = {0.f, 0.f, 0.f, 0.f}, w4_pend = {0.f, 0.f, 0.f, 0.f};
-  int grp_pend = 0;
+  int grp_pend = 0;  // 4 * group + the chain's first lane: the message index of the group's first candidate
   float best_pend = 0.0f;
+  const int g_lo = cs * LPC, g_hi = g_lo + 4 * (NG / 2);
+  const int w_base = b * WLD - cs * LPC;  // the lane's pairwise row, less what grp_pend carries
   auto locate = [&](auto sbp_c, const bool live) {
     constexpr int SBP = decltype(sbp_c)::value;
     if constexpr (RECOMP) {
       if (live) {
-        grp_pend = first_equal<NG>(c_prev, best_prev);
+        grp_pend = first_equal_sc_base<RECOMP ? NG : 8, 4>(c_prev, best_prev, g_lo, g_hi);
         best_pend = best_prev;
         // the step's messages are still in the row it read them from
-        m4_pend = *reinterpret_cast<const f4_t *>(&s_M[wib][(SBP & 1) * MROW + cs * KP + 4 * grp_pend]);
-        w4_pend = *reinterpret_cast<const f4_t *>(&s_W[rev][b * WLD + 4 * grp_pend]);
+        // (RECOMP has NS == 1, so the chain's first lane is also its first message)
+        m4_pend = *reinterpret_cast<const f4_t *>(&s_M[wib][(SBP & 1) * MROW + grp_pend]);
+        w4_pend = *reinterpret_cast<const f4_t *>(&s_W[rev][w_base + grp_pend]);
       }
     }
   };
@@ -353,7 +386,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       if constexpr (RECOMP) {
         const f4_t c4 = m4_pend + w4_pend;
         const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
-        arg = 4 * grp_pend + first_equal<4>(cc, best_pend);
+        arg = grp_pend | first_equal<4>(cc, best_pend);  // the lane that holds the source label
       } else {
         arg = s * A + first_equal<A>(c_prev, best_prev);
       }
@@ -377,7 +410,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     // With one or two chains per wavefront the byte stored is the LANE that
     // holds the source label (label + chain slot * lanes per chain): the
     // backtrack then uses it as a v_readlane selector as it stands.
-    if constexpr (CPW <= 2) arg += cs * LPC;
+    if constexpr (CPW <= 2 && !RECOMP) arg += cs * LPC;
     acc = __builtin_amdgcn_alignbit((unsigned)arg, acc, 8);
     if ((SBP & 3) == 3) {
       if (s == ((SBP >> 2) % NS)) keep = acc;
@@ -414,7 +447,12 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         // Unary energy of the labels this sweep starts from (one of the two
         // terms of Grid.cpp:1665-1680 for the previous solve): the operand is
         // in a register here, which saves the backtrack a gather per node.
-        unary_acc += (xown == b) ? (double)th_in : 0.0;
+        // selected in binary32 (one select instead of the two a binary64 select
+        // costs); the empty asm keeps the compiler from moving the select behind
+        // the conversion
+        float th_sel = (xown == b) ? th_in : 0.0f;
+        asm("" : "+v"(th_sel));
+        unary_acc += (double)th_sel;
         const float la = lam_in + p;                          // Tree.cpp:70
         if (FULL || tg + s < T) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(la), lam_rs, lane_off_st, goff, 0);
         th_own = rho * (th_in + la) + p;                      // Tree.cpp:85-86
