@@ -189,7 +189,8 @@ void launch_sweep_t(const ChainArgs &a, int blocks, hipStream_t s) {
   constexpr int GPB = (NS >= 4 || KP / NS >= 64) ? 4 : 8;
   // arg-min of 32+ candidates per lane, or a split chain (scarce chains, so
   // occupancy is not the limit): room for 256 registers
-  constexpr int MINW = (KP / NS >= 32 || NS > 1) ? 2 : 4;
+  // (8 or 16 labels packed several chains to a wavefront spill at 128 registers)
+  constexpr int MINW = (KP / NS >= 32 || NS > 1) ? 2 : (KP >= 8 ? 3 : 4);
   hipLaunchKernelGGL((chain_sweep_kernel<KP, NS, GPB, MINW, DUAL>), dim3(blocks), dim3(kChainBlock), 0, s, a);
 }
 

@@ -494,7 +494,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
           else if (tb > 0) finish(std::integral_constant<int, Q2>{}, tb - BLK, true);
           if (P >= 1) locate(std::integral_constant<int, Q1>{}, FULL || tb + Q1 < T);
           else if (tb > 0) locate(std::integral_constant<int, Q1>{}, true);
-          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_sched_barrier(0x6);
         } else if constexpr (PIPE) {
           if (j == 0 && u == 0) {
             if (tb > 0) finish(std::integral_constant<int, BLK - 1>{}, tb - BLK, true);
