@@ -161,6 +161,15 @@ __device__ __forceinline__ int first_equal_sc_base(const float *c, const float b
   return first_equal_sc<H, SC>(sel, best) | (in_lo ? lo : hi);
 }
 
+// First of four: v[i] for the lowest i with c[i] == best (the values are
+// registers, so an offset costs nothing).
+__device__ __forceinline__ int first_equal4_vals(const float *c, const float best, const int *v) {
+  int idx = v[3];
+#pragma unroll
+  for (int q = 2; q >= 0; q--) idx = (c[q] == best) ? v[q] : idx;
+  return idx;
+}
+
 // Cross-lane exchange between the NS lanes that share a target label.
 // Returns the partner's value for lane ^ d.
 template <int D>
@@ -198,6 +207,8 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // again from LDS (messages of the step, pairwise column of the lane).  That
   // replaces a select per candidate per halving level with two LDS reads.  The
   // messages of a step must then outlive the step: two alternating rows.
+  // (tried for the split k = 32 kernel too, 16 candidates per lane: slower, its
+  // single wavefront per SIMD feels the extra LDS traffic)
   constexpr bool RECOMP = !DUAL && NS == 1 && A >= 32;
   constexpr int NG = A / 4;      // candidate groups per lane
   constexpr int NB = RECOMP ? 2 : 1;
@@ -361,18 +372,25 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // and issues the reads of its four candidates, finish() compares them.
   typedef float f4_t __attribute__((ext_vector_type(4)));
   f4_t m4_pend = {0.f, 0.f, 0.f, 0.f}, w4_pend = {0.f, 0.f, 0.f, 0.f};
-  int grp_pend = 0;  // 4 * group + the chain's first lane: the message index of the group's first candidate
-  float best_pend = 0.0f;
-  const int g_lo = cs * LPC, g_hi = g_lo + 4 * (NG / 2);
+  // 4 * group + the lane's first source + the chain's first lane: the message
+  // index of the group's first candidate, and the lane that holds that source
+  int grp_pend = 0;
+  float best_pend = 0.0f, blo_pend = 0.0f, bhi_pend = 0.0f;
+  const int g_lo = cs * LPC + s * A, g_hi = g_lo + 4 * (NG / 2);
+  const int g_val[4] = {g_lo, g_lo + 4, g_lo + 8, g_lo + 12};  // four groups per lane: picked directly
   const int w_base = b * WLD - cs * LPC;  // the lane's pairwise row, less what grp_pend carries
   auto locate = [&](auto sbp_c, const bool live) {
     constexpr int SBP = decltype(sbp_c)::value;
     if constexpr (RECOMP) {
       if (live) {
-        grp_pend = first_equal_sc_base<RECOMP ? NG : 8, 4>(c_prev, best_prev, g_lo, g_hi);
+        if constexpr (NG >= 8) grp_pend = first_equal_sc_base<NG >= 8 ? NG : 8, 4>(c_prev, best_prev, g_lo, g_hi);
+        else grp_pend = first_equal4_vals(c_prev, best_prev, g_val);
         best_pend = best_prev;
-        // the step's messages are still in the row it read them from
-        // (RECOMP has NS == 1, so the chain's first lane is also its first message)
+        blo_pend = blo_prev;
+        bhi_pend = bhi_prev;
+        // the step's messages are still in the row it read them from (one
+        // chain per wavefront, or one lane per label: the chain's first lane
+        // is also its first message)
         m4_pend = *reinterpret_cast<const f4_t *>(&s_M[wib][(SBP & 1) * MROW + grp_pend]);
         w4_pend = *reinterpret_cast<const f4_t *>(&s_W[rev][w_base + grp_pend]);
       }
@@ -392,7 +410,9 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       }
       if constexpr (NS == 2 && KP == 32) {
         const auto ra = __builtin_amdgcn_permlane32_swap((unsigned)arg, (unsigned)arg, false, false);
-        arg = (bhi_prev < blo_prev) ? (int)ra[1] : (int)ra[0];  // ties keep the lower half's (lower) label
+        // ties keep the lower half's (lower) label
+        if constexpr (RECOMP) arg = (bhi_pend < blo_pend) ? (int)ra[1] : (int)ra[0];
+        else arg = (bhi_prev < blo_prev) ? (int)ra[1] : (int)ra[0];
       } else if constexpr (NS > 1) {
         // partner values were exchanged when the minimum was combined; redo
         // the same comparisons on the (minimum, label) pairs
@@ -484,7 +504,10 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
           pth[j] = buf_load(th_rs, poff);
           plam[j] = buf_load(lam_rs, poff);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        // memory instructions stay where they are written; with one wavefront
+        // per SIMD (a split chain) letting ALU work cross pays, with two it does not
+        if constexpr (NS > 1) __builtin_amdgcn_sched_barrier(0x6);
+        else __builtin_amdgcn_sched_barrier(0);
         // (b) ... while the previous step's back-pointer is worked out
         if constexpr (RECOMP) {
           // compare for the step two back, then locate for the step one back
