@@ -109,13 +109,38 @@ __device__ __forceinline__ float min_of(const float *c) {
   return r;
 }
 
+// V0 * [c0 == best] else V1 * [c1 == best] else V2 * [c2 == best] else V3: the
+// first of four candidates that equals the minimum, as a scaled index.  Three
+// compares into three masks, then three selects: written out because a select
+// may not read a mask in the two issue slots after the compare that writes it,
+// and the compiler pairs every compare with its select and pads with s_nop.
+template <int V0, int V1, int V2, int V3>
+__device__ __forceinline__ int first_of_four(const float c0, const float c1, const float c2, const float best) {
+  int idx;
+  unsigned long long m1, m2;
+  asm("v_cmp_eq_f32_e64 %[m2], %[c2], %[best]\n\t"
+      "v_cmp_eq_f32_e64 %[m1], %[c1], %[best]\n\t"
+      "v_cmp_eq_f32_e32 vcc, %[c0], %[best]\n\t"
+      "v_cndmask_b32_e64 %[idx], %[v3], %[v2], %[m2]\n\t"
+      "v_cndmask_b32_e64 %[idx], %[idx], %[v1], %[m1]\n\t"
+      "v_cndmask_b32_e64 %[idx], %[idx], %[v0], vcc"
+      : [idx] "=&v"(idx), [m1] "=&s"(m1), [m2] "=&s"(m2)
+      : [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [best] "v"(best), [v0] "n"(V0), [v1] "n"(V1), [v2] "n"(V2), [v3] "n"(V3)
+      : "vcc");
+  return idx;
+}
+
 // Lowest index i in [0, N) with c[i] == best, given that one exists.  A flat
 // scan costs a compare and a select per candidate; halving the candidate set
 // on "is the minimum in the lower half" costs one compare per level and a
 // select per surviving candidate, about two thirds of that.
-template <int N>
+// HAND: the last four go through first_of_four (pays with one wavefront per
+// SIMD, costs with two: the group scheme's vector loads get split).
+template <int N, bool HAND = false>
 __device__ __forceinline__ int first_equal(const float *c, const float best) {
-  if constexpr (N <= 4) {
+  if constexpr (N == 4 && HAND) {
+    return first_of_four<0, 1, 2, 3>(c[0], c[1], c[2], best);
+  } else if constexpr (N <= 4) {
     int idx = N - 1;
 #pragma unroll
     for (int q = N - 2; q >= 0; q--) idx = (c[q] == best) ? q : idx;
@@ -126,7 +151,7 @@ __device__ __forceinline__ int first_equal(const float *c, const float best) {
     float sel[H];
 #pragma unroll
     for (int q = 0; q < H; q++) sel[q] = in_lo ? c[q] : c[H + q];
-    const int r = first_equal<H>(sel, best);
+    const int r = first_equal<H, HAND>(sel, best);
     return r | (in_lo ? 0 : H);
   }
 }
@@ -406,7 +431,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
         arg = grp_pend | first_equal<4>(cc, best_pend);  // the lane that holds the source label
       } else {
-        arg = s * A + first_equal<A>(c_prev, best_prev);
+        arg = s * A + first_equal<A, (NS > 1)>(c_prev, best_prev);
       }
       if constexpr (NS == 2 && KP == 32) {
         const auto ra = __builtin_amdgcn_permlane32_swap((unsigned)arg, (unsigned)arg, false, false);
