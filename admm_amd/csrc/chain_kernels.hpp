@@ -583,7 +583,9 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
             const auto rb = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
             blo_prev = __uint_as_float(rb[0]);
             bhi_prev = __uint_as_float(rb[1]);
-            best = __builtin_fminf(blo_prev, bhi_prev);
+            // plain v_min_f32: through the builtin the compiler first canonicalises
+            // both operands (it cannot see that the swapped bits are ordinary floats)
+            asm("v_min_f32_e32 %0, %1, %2" : "=v"(best) : "v"(blo_prev), "v"(bhi_prev));
           } else {
 #pragma unroll
             for (int d = KP; d < LPC; d <<= 1) best = __builtin_fminf(best, __shfl_xor(best, d));

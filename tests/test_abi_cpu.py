@@ -87,6 +87,10 @@ def test_create_rejects_bad_arguments_and_reports_why():
     d.solver, d.batch = 1, 3
     assert lib.admm_create(C.byref(d), C.byref(h)) == -1
     assert b"batch" in lib.admm_last_error(None)
+    # a column chain whose half would span 4 GiB or more is refused, not wrapped
+    d.batch, d.nranks, d.rows, d.cols, d.k = 1, 1, 70000, 1000, 32
+    assert lib.admm_create(C.byref(d), C.byref(h)) == -1
+    assert b"too large" in lib.admm_last_error(None)
 
 
 def test_no_cpu_fallback():

@@ -67,6 +67,12 @@ def test_config_512x512_k16_trunc_linear():
     _run(512, 512, 16, "trunc_linear", 10)
 
 
+def test_tall_grid_far_offsets():
+    """Beyond the benchmark sizes: 6001 x 1500, k = 32 (1.15 GB per operand array, odd chain
+    length): the column chains step 192 kB at a time through ~0.6 GB of descriptor range."""
+    _run(6001, 1500, 32, "dense", 2, seed=77)
+
+
 def test_config_batch_256_grids_256x256_k8():
     from oracle import oracle as O
     import admm_amd as A
