@@ -54,16 +54,31 @@ int load_info(const std::string &path, ncfile::Header *h, admm_graphfile_info *i
   return ADMM_GF_OK;
 }
 
+// A caller sizes its buffers from the sizes read_info reports: a variable
+// whose own dimensions say otherwise must not be read into them.
+bool shape_ok(const ncfile::Header &h, const admm_graphfile_info &info, const ncfile::Var &v) {
+  const bool node = v.name == "verticePotentials", list = v.name == "edgeList";
+  const int64_t want_rows = node ? info.num_vertices : info.num_edges;
+  const int64_t want_width = list ? 2 : (node ? info.k : info.k2);
+  if (v.dimids.size() != 2) return false;
+  for (int64_t id : v.dimids) if (id < 0 || id >= (int64_t)h.dims.size()) return false;
+  return h.dims[(size_t)v.dimids[0]].len == want_rows && h.dims[(size_t)v.dimids[1]].len == want_width;
+}
+
 int read_var(const char *path, const char *var, int64_t first, int64_t count, void *out, bool negate) {
   if (!path || (!out && count > 0)) return fail(ADMM_GF_E_ARG, "null argument");
   ncfile::Header h;
   std::string err;
-  if (!ncfile::read_header(path, &h, &err)) return fail(ADMM_GF_E_FORMAT, err);
+  admm_graphfile_info info;
+  const int rc = load_info(path, &h, &info);
+  if (rc) return rc;
   const ncfile::Var *v = h.find_var(var);
   if (!v) return fail(ADMM_GF_E_FORMAT, std::string("'") + path + "' has no variable '" + var + "'");
+  const bool is_list = strcmp(var, "edgeList") == 0;
   const bool is_float = v->type == ncfile::NC_FLOAT;
-  if ((strcmp(var, "edgeList") == 0) == is_float)
+  if (is_list == is_float || (is_list && v->type != ncfile::NC_INT))
     return fail(ADMM_GF_E_FORMAT, std::string("variable '") + var + "' has the wrong type");
+  if (!shape_ok(h, info, *v)) return fail(ADMM_GF_E_FORMAT, std::string("variable '") + var + "' of '" + path + "' does not have the shape the file's sizes state");
   if (!ncfile::read_rows(path, h, var, first, count, out, &err)) return fail(ADMM_GF_E_IO, err);
   if (negate && is_float) {
     const int64_t n = count * h.dims[(size_t)v->dimids[1]].len;
@@ -155,6 +170,9 @@ int admm_graphfile_shared_table(const char *path, float *table, int negate, int 
   if (rc) return rc;
   *shared = 0;
   if (info.num_edges < 1 || info.k2 < 1) return fail(ADMM_GF_E_FORMAT, std::string("'") + path + "' has no edges");
+  const ncfile::Var *ev = h.find_var("edgePotentials");
+  if (!ev || ev->type != ncfile::NC_FLOAT || !shape_ok(h, info, *ev))
+    return fail(ADMM_GF_E_FORMAT, std::string("variable 'edgePotentials' of '") + path + "' does not have the shape the file's sizes state");
   std::string err;
   std::vector<float> first((size_t)info.k2);
   if (!ncfile::read_rows(path, h, "edgePotentials", 0, 1, first.data(), &err)) return fail(ADMM_GF_E_IO, err);

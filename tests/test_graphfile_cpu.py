@@ -313,3 +313,55 @@ def test_errors(tmp_path):
     cut.write_bytes(blob[:-8])  # inside the last variable
     with pytest.raises(GF.GraphFileError):
         GF.read_unaries(cut)
+
+
+def test_variable_shape_must_match_the_stated_sizes(tmp_path):
+    """A caller sizes its buffers from the sizes the file states; a variable whose own
+    dimensions disagree (here: three end points per edge) is refused, not read."""
+    f = tmp_path / "odd.nc"
+    with netcdf_file(str(f), "w", version=1) as nc:
+        nc.createDimension("numVertices", 4)
+        nc.createDimension("numVerticePotentials", 2)
+        nc.createDimension("numEdges", 3)
+        nc.createDimension("numEdgePotentials", 4)
+        nc.createDimension("numEndPointsPerEdge", 3)
+        nc.createVariable("edgeList", "i4", ("numEdges", "numEndPointsPerEdge"))[:] = np.zeros((3, 3), dtype=np.int32)
+        nc.createVariable("edgePotentials", "f4", ("numEdges", "numEdgePotentials"))[:] = np.zeros((3, 4), dtype=np.float32)
+        nc.createVariable("verticePotentials", "f4", ("numVertices", "numVerticePotentials"))[:] = np.ones((4, 2), dtype=np.float32)
+        nc.numEdges = np.int32(5)  # the attribute disagrees with the dimension
+    with pytest.raises(GF.GraphFileError) as e:
+        GF.read_edges(f, 0, 3)
+    assert e.value.code == -3
+    with pytest.raises(GF.GraphFileError):
+        GF.read_pairwise(f, 0, 3)
+    assert np.array_equal(GF.read_unaries(f, negate=False), np.ones((4, 2), dtype=np.float32))
+
+
+def test_reader_survives_truncation_and_corruption(tmp_path):
+    """Every prefix of a valid file and a few hundred corrupted headers: an error or a
+    result, never a fault."""
+    el, un, pw = _problem(3, 4, 3, seed=21)
+    good = tmp_path / "good.nc"
+    bad = tmp_path / "bad.nc"
+    rng = np.random.default_rng(5)
+    for version in (1, 5):
+        GF.write(good, 12, el, un, pw, rows=3, cols=4, version=version)
+        blob = good.read_bytes()
+        cases = [blob[:n] for n in range(0, min(len(blob), 520), 3)]
+        for _ in range(300):
+            b = bytearray(blob)
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(0, min(len(b), 500)))] = int(rng.integers(0, 256))
+            cases.append(bytes(b))
+        for c in cases:
+            bad.write_bytes(c)
+            try:
+                info = GF.read_info(bad)
+                if not (0 <= info.num_edges <= 1000 and 0 <= info.num_vertices <= 1000 and 0 < info.k <= 64 and 0 < info.k2 <= 4096):
+                    continue
+                GF.read_edges(bad)
+                GF.read_unaries(bad)
+                GF.read_pairwise(bad)
+                GF.shared_table(bad)
+            except GF.GraphFileError:
+                pass
