@@ -64,7 +64,7 @@ _ip = C.POINTER(C.c_int32)
 
 def _ck(rc):
     if rc != 0:
-        raise GraphFileError(rc, (lib.admm_graphfile_last_error() or b"").decode())
+        raise GraphFileError(rc, (lib.admm_graphfile_last_error() or b"").decode("utf-8", "replace"))
 
 
 def _path(p):
