@@ -385,6 +385,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   constexpr int NPREV = RECOMP ? NG : A;
   float c_prev[NPREV];  // candidates of the step, or the minima of their groups
   float best_prev = 0.0f, blo_prev = 0.0f, bhi_prev = 0.0f;
+  float qlo_prev = 0.0f, qhi_prev = 0.0f;  // four lanes per label: the first (row) level of the combine
 #pragma unroll
   for (int q = 0; q < NPREV; q++) c_prev[q] = 0.0f;
 
@@ -438,6 +439,13 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         // ties keep the lower half's (lower) label
         if constexpr (RECOMP) arg = (bhi_pend < blo_pend) ? (int)ra[1] : (int)ra[0];
         else arg = (bhi_prev < blo_prev) ? (int)ra[1] : (int)ra[0];
+      } else if constexpr (NS == 4 && KP == 16) {
+        // rows s = 0..3 of sixteen lanes hold the four slices of a label's
+        // sources: first rows 0|1 and 2|3 (one row swap), then the halves
+        const auto r1 = __builtin_amdgcn_permlane16_swap((unsigned)arg, (unsigned)arg, false, false);
+        arg = (qhi_prev < qlo_prev) ? (int)r1[1] : (int)r1[0];
+        const auto r2 = __builtin_amdgcn_permlane32_swap((unsigned)arg, (unsigned)arg, false, false);
+        arg = (bhi_prev < blo_prev) ? (int)r2[1] : (int)r2[0];
       } else if constexpr (NS > 1) {
         // partner values were exchanged when the minimum was combined; redo
         // the same comparisons on the (minimum, label) pairs
@@ -585,6 +593,16 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
             bhi_prev = __uint_as_float(rb[1]);
             // plain v_min_f32: through the builtin the compiler first canonicalises
             // both operands (it cannot see that the swapped bits are ordinary floats)
+            asm("v_min_f32_e32 %0, %1, %2" : "=v"(best) : "v"(blo_prev), "v"(bhi_prev));
+          } else if constexpr (NS == 4 && KP == 16) {
+            // two register swaps instead of two shuffles through LDS
+            const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+            qlo_prev = __uint_as_float(q[0]);
+            qhi_prev = __uint_as_float(q[1]);
+            asm("v_min_f32_e32 %0, %1, %2" : "=v"(best) : "v"(qlo_prev), "v"(qhi_prev));
+            const auto rb = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+            blo_prev = __uint_as_float(rb[0]);
+            bhi_prev = __uint_as_float(rb[1]);
             asm("v_min_f32_e32 %0, %1, %2" : "=v"(best) : "v"(blo_prev), "v"(bhi_prev));
           } else {
 #pragma unroll
