@@ -916,14 +916,18 @@ ExchangePlan make_plan(const admm_ctx *c) {
 }
 
 // Gathers the strided label blocks into sendbuf (queued on the context's stream).
-int pack_labels(admm_ctx *c, const ExchangePlan &p) {
+// own_direct: this rank's own blocks go straight into its receive arrays (label
+// mode only; the caller then leaves itself out of the exchange).
+int pack_labels(admm_ctx *c, const ExchangePlan &p, bool own_direct = false) {
   const admm_desc &d = c->d;
   const int nr = c->st.nrows, nc = c->st.ncols;
   int *send_a = c->sendbuf, *send_b = c->sendbuf + p.off_a[d.nranks];
   const long long total = (long long)nr * d.cols + (long long)nc * d.rows;
   if (total > 0)
     hipLaunchKernelGGL(pack_strip_labels_kernel, dim3(grid_for(total, 256)), dim3(256), 0, c->stream, send_a, send_b,
-                       c->xrow_r, c->xcolT_c, nr, nc, d.rows, d.cols, d.nranks);
+                       c->xrow_r, c->xcolT_c, nr, nc, d.rows, d.cols, d.nranks, d.rank,
+                       own_direct ? c->xrow_c + (size_t)p.r0[d.rank] * nc : nullptr,
+                       own_direct ? c->xcolT_r + (size_t)p.c0[d.rank] * nr : nullptr);
   if (d.exchange == ADMM_EXCHANGE_DENSE) {
     const long long n = p.off_a[d.nranks] + p.off_b[d.nranks];
     if (n > 0)
@@ -1019,15 +1023,26 @@ int admm_communicate(admm_ctx *c) {
   const int G = d.nranks;
   const int nr = c->st.nrows, nc = c->st.ncols;
   const ExchangePlan p = make_plan(c);
-  if ((rc = pack_labels(c, p))) return rc;
+  const bool own_direct = d.exchange == ADMM_EXCHANGE_LABELS;
+  if ((rc = pack_labels(c, p, own_direct))) return rc;
   const Wire w = wire_of(c);
   const size_t m = (size_t)w.m;
   const int32_t *send_a = w.send, *send_b = w.send + p.off_a[G] * m;
   // Both kinds of block arrive contiguous on the other side: region a is
   // [rows][nc] (a block = whole rows of it) and region b is [cols][nr].
   // Elements travel as 4-byte words whatever they hold.
+  // my own blocks stay on the device, no send to self: the pack kernel has
+  // already put them in place, or (dense mode) a plain copy does
+  if (!own_direct) {
+    const int h = d.rank;
+    if ((long long)nr * p.nc[h] > 0)
+      HIP_TRY(c, hipMemcpyAsync(w.recv_a + (size_t)p.r0[h] * nc * m, send_a + p.off_a[h] * m, (size_t)nr * p.nc[h] * m * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    if ((long long)nc * p.nr[h] > 0)
+      HIP_TRY(c, hipMemcpyAsync(w.recv_b + (size_t)p.c0[h] * nr * m, send_b + p.off_b[h] * m, (size_t)nc * p.nr[h] * m * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  }
   NCCL_TRY(c, ncclGroupStart());
   for (int h = 0; h < G; h++) {
+    if (h == d.rank) continue;
     if ((long long)nr * p.nc[h] > 0) NCCL_TRY(c, ncclSend(send_a + p.off_a[h] * m, (size_t)nr * p.nc[h] * m, ncclInt32, h, c->comm, s));
     if ((long long)p.nr[h] * nc > 0) NCCL_TRY(c, ncclRecv(w.recv_a + (size_t)p.r0[h] * nc * m, (size_t)p.nr[h] * nc * m, ncclInt32, h, c->comm, s));
     if ((long long)nc * p.nr[h] > 0) NCCL_TRY(c, ncclSend(send_b + p.off_b[h] * m, (size_t)nc * p.nr[h] * m, ncclInt32, h, c->comm, s));
@@ -1177,7 +1192,8 @@ int admm_communicate_group(admm_ctx **ctxs, int n) {
     admm_ctx *c = ctxs[g];
     if ((rc = check_ctx(c))) return rc;
     plans.push_back(make_plan(c));
-    if ((rc = pack_labels(c, plans[g]))) return rc;
+    // label mode: a strip's own blocks go straight into its receive arrays (as in admm_communicate)
+    if ((rc = pack_labels(c, plans[g], c->d.exchange == ADMM_EXCHANGE_LABELS))) return rc;
     if (!c->ev_packed) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
     if (!c->ev_pulled) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_pulled, hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(c->ev_packed, c->stream));
@@ -1190,6 +1206,7 @@ int admm_communicate_group(admm_ctx **ctxs, int n) {
     for (int g = 0; g < n; g++) {
       admm_ctx *sd = ctxs[g];
       const ExchangePlan &p = plans[g];
+      if (g == h && r->d.exchange == ADMM_EXCHANGE_LABELS) continue;  // already in place
       HIP_TRY(r, hipStreamWaitEvent(r->stream, sd->ev_packed, 0));
       const Wire ws = wire_of(sd), wr = wire_of(r);
       const size_t m = (size_t)ws.m;

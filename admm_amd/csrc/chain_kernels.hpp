@@ -1158,23 +1158,27 @@ __device__ __forceinline__ int owner_of(int i, int n, int G, int *start, int *co
 // [nr][nc_h]; b-blocks: my column-chain labels xcolT[nc][rows] cut by the
 // peers' row strips, block h = [nc][nr_h].  The blocks of a kind lie in rank
 // order, so block h of the a-kind starts at nr * c0_h and of the b-kind at
-// nc * r0_h.
+// nc * r0_h.  With own_a / own_b set, the blocks this rank would send to
+// itself (rank self) go straight to where it would receive them.
 __global__ void pack_strip_labels_kernel(int *__restrict__ send_a, int *__restrict__ send_b,
                                          const int *__restrict__ xrow, const int *__restrict__ xcolT,
-                                         int nr, int nc, int rows, int cols, int G) {
+                                         int nr, int nc, int rows, int cols, int G, int self,
+                                         int *__restrict__ own_a, int *__restrict__ own_b) {
   const long long na = (long long)nr * cols, nb = (long long)nc * rows;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < na + nb;
        i += (long long)gridDim.x * blockDim.x) {
     int st, cnt;
     if (i < na) {
       const int r = (int)(i / cols), cidx = (int)(i % cols);
-      owner_of(cidx, cols, G, &st, &cnt);
-      send_a[(long long)nr * st + (long long)r * cnt + (cidx - st)] = xrow[i];
+      const int h = owner_of(cidx, cols, G, &st, &cnt);
+      int *dst = (own_a && h == self) ? own_a : send_a + (long long)nr * st;
+      dst[(long long)r * cnt + (cidx - st)] = xrow[i];
     } else {
       const long long j = i - na;
       const int cc = (int)(j / rows), ridx = (int)(j % rows);
-      owner_of(ridx, rows, G, &st, &cnt);
-      send_b[(long long)nc * st + (long long)cc * cnt + (ridx - st)] = xcolT[j];
+      const int h = owner_of(ridx, rows, G, &st, &cnt);
+      int *dst = (own_b && h == self) ? own_b : send_b + (long long)nc * st;
+      dst[(long long)cc * cnt + (ridx - st)] = xcolT[j];
     }
   }
 }
