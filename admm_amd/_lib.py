@@ -23,7 +23,7 @@ EXPORTS = [
     "admm_exchange_unpack_host", "admm_update",
     "admm_linear_objective", "admm_objective", "admm_objective_enqueue", "admm_objective_read", "admm_synchronize", "admm_finalize",
     "admm_download_labels", "admm_download_consensus", "admm_download_state",
-    "admm_state_size", "admm_partition", "admm_strip_info", "admm_edge_local_info", "admm_edge_local_vertices",
+    "admm_state_size", "admm_partition", "admm_strip_info", "admm_edge_local_info", "admm_edge_local_vertices", "admm_edge_plan",
     "admm_comm_get_unique_id",
     "admm_comm_init", "admm_lcg_fill", "admm_grid_edges", "admm_profile_reset",
     "admm_profile_read", "admm_device_count", "admm_version",
@@ -84,6 +84,7 @@ def _load():
         "admm_strip_info": (C.c_int, [vp] + [C.POINTER(C.c_int)] * 4),
         "admm_edge_local_info": (C.c_int, [vp] + [C.POINTER(C.c_int)] * 3),
         "admm_edge_local_vertices": (C.c_int, [vp, ip]),
+        "admm_edge_plan": (C.c_int, [ip, C.c_int, C.c_int, C.c_int, ip, ip, ip, ip, ip, ip, ip]),
         "admm_comm_get_unique_id": (C.c_int, [vp]),
         "admm_comm_init": (C.c_int, [vp, vp]),
         "admm_lcg_fill": (C.c_uint32, [C.c_uint32, C.c_int64, fp]),

@@ -663,6 +663,31 @@ int admm_destroy(admm_ctx *c) {
   return ADMM_OK;
 }
 
+int admm_edge_plan(const int32_t *edge_list, int num_edges, int nranks, int rank, int32_t *info,
+                   int32_t *verts, int32_t *counts, int32_t *neigh_ranks, int32_t *neigh_off,
+                   int32_t *shared_local, int32_t *shared_counts) {
+  if (!info || num_edges < 0 || (!edge_list && num_edges > 0) || nranks < 1 || rank < 0 || rank >= nranks)
+    return fail(nullptr, ADMM_E_ARG, "bad argument");
+  admm_ctx c;  // host fields only: no device is touched
+  c.d.nranks = nranks;
+  c.d.rank = rank;
+  c.Eglobal = c.E = num_edges;
+  c.h_edges.assign(edge_list, edge_list + 2 * (size_t)num_edges);
+  edge_partition(&c);
+  info[0] = c.e0; info[1] = c.E; info[2] = c.V; info[3] = (int)c.nb_rank.size(); info[4] = (int)c.h_send_idx.size();
+  for (int v = 0; v < c.V; v++) {
+    if (verts) verts[v] = c.h_lverts[v];
+    if (counts) counts[v] = c.h_cnt[v];
+  }
+  for (size_t q = 0; q < c.nb_rank.size(); q++) if (neigh_ranks) neigh_ranks[q] = c.nb_rank[q];
+  for (size_t q = 0; q < c.nb_off.size(); q++) if (neigh_off) neigh_off[q] = c.nb_off[q];
+  for (size_t p = 0; p < c.h_send_idx.size(); p++) {
+    if (shared_local) shared_local[p] = c.h_send_idx[p];
+    if (shared_counts) shared_counts[p] = c.h_nb_cnt[p];
+  }
+  return ADMM_OK;
+}
+
 int admm_edge_local_info(const admm_ctx *c, int *edge0, int *nedges, int *nverts) {
   if (!c || is_chain(c)) return ADMM_E_ARG;
   if (edge0) *edge0 = c->e0;

@@ -345,6 +345,27 @@ class Grid:
             raise AdmmError(rc, (lib.admm_last_error(self._h) or b"").decode())
 
 
+def edge_plan(edge_list, nranks, rank):
+    """The edge solver's exchange plan for one rank (GetVerts + InitNeighborsByEdge,
+    Grid.cpp:815-856, 198-331); host arithmetic only, no device.  Returns a dict:
+    edge0, nedges, verts, counts, neighbours (ranks, ascending), and per neighbour the
+    shared local vertex ids and that neighbour's copy counts."""
+    el = np.ascontiguousarray(edge_list, dtype=np.int32).reshape(-1)
+    info = np.zeros(5, dtype=np.int32)
+    null = C.POINTER(C.c_int32)()
+    p = lambda a: a.ctypes.data_as(_ip)
+    rc = lib.admm_edge_plan(p(el), el.size // 2, nranks, rank, p(info), null, null, null, null, null, null)
+    if rc != 0:
+        raise AdmmError(rc, (lib.admm_last_error(None) or b"").decode())
+    e0, ne, nv, nn, ns = (int(x) for x in info)
+    verts, counts = np.zeros(max(nv, 1), np.int32), np.zeros(max(nv, 1), np.int32)
+    nr, no = np.zeros(max(nn, 1), np.int32), np.zeros(nn + 1, np.int32)
+    sl, sc = np.zeros(max(ns, 1), np.int32), np.zeros(max(ns, 1), np.int32)
+    lib.admm_edge_plan(p(el), el.size // 2, nranks, rank, p(info), p(verts), p(counts), p(nr), p(no), p(sl), p(sc))
+    return {"edge0": e0, "nedges": ne, "verts": verts[:nv], "counts": counts[:nv], "neighbours": nr[:nn],
+            "shared": [sl[no[q]:no[q + 1]] for q in range(nn)], "shared_counts": [sc[no[q]:no[q + 1]] for q in range(nn)]}
+
+
 def communicate_group(grids):
     """Label exchange between the strips of one problem held by this process
     (Grid objects in rank order)."""

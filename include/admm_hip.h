@@ -183,6 +183,18 @@ int admm_strip_info(const admm_ctx *ctx, int *row0, int *nrows, int *col0, int *
  * the row order of admm_download_consensus (vSelfVec). */
 int admm_edge_local_info(const admm_ctx *ctx, int *edge0, int *nedges, int *nverts);
 int admm_edge_local_vertices(const admm_ctx *ctx, int32_t *ids);
+/* The exchange plan admm_create builds for rank `rank` of `nranks` from the
+ * whole edge list (GetVerts + InitNeighborsByEdge, Grid.cpp:815-856, 198-331):
+ * pure host arithmetic, no device.  info[5] = first edge, edges, distinct
+ * vertices, neighbouring ranks, shared entries in total.  The arrays may be
+ * NULL (call once for the sizes): verts / counts = global id and global copy
+ * count (vertCnt after Grid.cpp:309-319) per local vertex; neigh_ranks
+ * ascending, neigh_off[q] .. neigh_off[q+1] = neighbour q's entries of
+ * shared_local (local vertex ids, ascending: outNeighborMapEdge) and
+ * shared_counts (that neighbour's own copy count of the vertex). */
+int admm_edge_plan(const int32_t *edge_list, int num_edges, int nranks, int rank, int32_t *info,
+                   int32_t *verts, int32_t *counts, int32_t *neigh_ranks, int32_t *neigh_off,
+                   int32_t *shared_local, int32_t *shared_counts);
 
 /* Multi-GPU bootstrap.  Rank 0 fills a 128-byte RCCL id, the caller ships it
  * to every rank by its own means (the reference's is MPI_Init), and every

@@ -78,3 +78,55 @@ def test_strips_equal_single_rank(tmp_path, world, R, C, k, pairwise):
         assert np.array_equal(g["labels"], ref.labels()[r0:r0 + nr])
         assert np.array_equal(g["lam_row"], ref.lambda_row[r0:r0 + nr])
         assert np.array_equal(g["lam_col"], ref.lambda_col[:, c0:c0 + nc])
+
+
+# ---- edge solver on several ranks: the exchange plan, host arithmetic only ----
+
+def _plan_cases():
+    from oracle import oracle as O
+    rng = np.random.default_rng(8)
+    yield "grid 9x7", 63, O.grid_edges(9, 7)
+    yield "grid 2x2", 4, O.grid_edges(2, 2)
+    V = 40
+    el = np.array([(i, i + 1) for i in range(V - 1)] + [(int(a), int(b)) for a, b in rng.integers(0, V, size=(30, 2)) if a != b],
+                  dtype=np.int32).reshape(-1)
+    yield "chain plus random chords", V, el
+    yield "two components with a gap", 20, np.array([0, 1, 1, 2, 2, 3, 10, 11, 11, 12, 12, 19], dtype=np.int32)
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 4, 7, 16])
+def test_edge_exchange_plan_matches_the_restatement(P):
+    """admm_edge_plan (what every rank builds in admm_create, no device needed) against the
+    P-rank restatement of GetVerts / InitNeighborsByEdge (Grid.cpp:815-856, 198-331): edge
+    slices, vertex sets, global copy counts; and the plans of two neighbouring ranks list
+    the same shared vertices in the same order, which is what makes their messages match."""
+    import admm_amd as A
+    from oracle import oracle as O
+    for name, V, el in _plan_cases():
+        E = el.size // 2
+        k = 2
+        o = O.EdgeRanksOracle(V, el, k, np.zeros((V, k), np.float32), np.zeros((E, k * k), np.float32), P)
+        plans = [A.edge_plan(el, P, r) for r in range(P)]
+        seen = 0
+        for r, pl in enumerate(plans):
+            assert pl["edge0"] == seen, name
+            seen += pl["nedges"]
+            ids, cnt, _ = o.rank_vertices(r)
+            assert np.array_equal(pl["verts"], ids), name
+            assert np.array_equal(pl["counts"], cnt), name
+            assert list(pl["neighbours"]) == sorted(pl["neighbours"]) and r not in pl["neighbours"], name
+            for q, h in enumerate(pl["neighbours"]):
+                other = plans[h]
+                assert r in other["neighbours"], name
+                qq = list(other["neighbours"]).index(r)
+                mine = pl["verts"][pl["shared"][q]]
+                theirs = other["verts"][other["shared"][qq]]
+                assert np.array_equal(mine, theirs) and np.array_equal(mine, np.sort(mine)), name
+                # what I am told the neighbour holds: the vertex's copies in ITS edge slice
+                sl = el[2 * other["edge0"]:2 * (other["edge0"] + other["nedges"])]
+                assert np.array_equal(pl["shared_counts"][q], np.array([(sl == v).sum() for v in mine], dtype=np.int32)), name
+        assert seen == E, name
+        # global copy count = degree in the whole graph
+        deg = np.bincount(el, minlength=V)
+        for pl in plans:
+            assert np.array_equal(pl["counts"], deg[pl["verts"]]), name
