@@ -1,8 +1,9 @@
 // Chain (min-sum / Viterbi) solver kernels for gfx950.
 //
-// Trees are the row chains and the column chains of the grid.  One wavefront
-// sweeps one chain with the label dimension across lanes (several short-label
-// chains share a wavefront when k is small).  The ADMM shell around the sweep
+// Trees are the row chains and the column chains of the grid.  A wavefront
+// sweeps half a chain with the label dimension across lanes (several
+// short-label half chains share a wavefront when k is small), and the two
+// wavefronts of a chain meet in its middle.  The ADMM shell around the sweep
 // keeps the reference's formulas and operation order:
 //   dual update      lambda += penalty * (mu - m)                  Tree.cpp:70
 //   potential adjust t = rho*(theta + lambda) - penalty*(m - mu)   Tree.cpp:85-86
@@ -195,13 +196,6 @@ __device__ __forceinline__ int first_equal4_vals(const float *c, const float bes
   return idx;
 }
 
-// Cross-lane exchange between the NS lanes that share a target label.
-// Returns the partner's value for lane ^ d.
-template <int D>
-__device__ __forceinline__ float xor_lane_f(float v) { return __shfl_xor(v, D); }
-template <int D>
-__device__ __forceinline__ int xor_lane_i(int v) { return __shfl_xor(v, D); }
-
 // KP   : labels padded to a power of two (lanes b >= k idle with M = +inf)
 // NS   : lanes that share one target label; lane s of them scans the source
 //        labels [s*KP/NS, (s+1)*KP/NS) and holds the node operands of the
@@ -213,8 +207,9 @@ __device__ __forceinline__ int xor_lane_i(int v) { return __shfl_xor(v, D); }
 //
 // Back-pointers: byte (t, b) = lowest source label attaining the minimum for
 // target b at step t.  They are packed four steps to a dword and written
-// straight from registers, dword (t/4)*KP + b of the chain's scratch; the
-// backtrack streams them back through LDS one 64-step chunk at a time.
+// straight from registers, dword (t/4)*KP + b of the half chain's scratch;
+// the backtrack streams them back one 64-step chunk at a time (t counts the
+// steps of the half chain in sweep order).
 template <int KP, int NS, int GPB, int MINW, bool DUAL>
 __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const ChainArgs args) {
   constexpr int LPC = KP * NS;   // lanes per chain
