@@ -160,11 +160,31 @@ def main():
             flag = torch.tensor([ok], dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag[0]) == 1:
+                # one untimed probe iteration: an exchange that fails on any rank
+                # sends everybody to the host-staged transport instead of
+                # leaving the others waiting at a barrier
+                try:
+                    g.Compute(); g.Communicate(); g.Update(); g.Synchronize()
+                except A.AdmmError as e:
+                    ok = 0
+                    sys.stderr.write("rank %d: RCCL exchange failed: %s\n" % (rank, e))
+                flag = torch.tensor([ok], dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag[0]) == 1:
                 transport = "rccl"
             elif transport == "rccl":
-                sys.exit("RCCL bootstrap failed and --transport rccl was requested")
+                sys.exit("RCCL failed and --transport rccl was requested")
             else:
                 transport = "host"
+                g.close()
+                g = A.Grid(rank=rank, nprocs=nprocs_for_grid, device=local_rank % ndev)
+                g.SetPartitioner(A.ROW)
+                g.SetPenalties(0.5, 1.0)
+                g.SetGlobalInfo(rows, cols, k, batch=my_batch)
+                g.exchange = 0 if args.exchange == "labels" else 1
+                g.Generate(seed=args.seed + b0, pairwise=pairwise)
+                g.InitOptimization()
+                g._unary = None
 
     def barrier():
         g.Synchronize()
