@@ -169,6 +169,22 @@ class Grid:
         graphfile.write(fname, V, el, -self._unary, pw.reshape(-1, self.k * self.k) if self._per_edge else pw.reshape(self.k, self.k),
                         rows=self.rows, cols=self.cols, version=version)
 
+    def Convert(self, manifest):
+        """Grid::Convert (Grid.cpp:985-1045): raw binary files named by a four-line manifest
+        -> this object; follow with Save, as Converter.cpp does.  The raw files hold what a
+        graph file holds (scores), so this object keeps their negation, as after any Load."""
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            tmp = os.path.join(td, "converted.nc")
+            graphfile.convert(manifest, tmp)
+            keep = self.part
+            self.part = EDGE
+            try:
+                self.k = 0
+                self._load_file(tmp)
+            finally:
+                self.part = keep
+
     def Generate(self, seed=1234, pairwise="potts"):
         """Synthetic potentials: LCG unaries in [0,1) drawn node-major, grid g
         of a batch seeded with seed+g, and a named pairwise table."""

@@ -365,3 +365,26 @@ def test_reader_survives_truncation_and_corruption(tmp_path):
                 GF.shared_table(bad)
             except GF.GraphFileError:
                 pass
+
+
+def test_grid_convert_then_save_keeps_the_raw_values(tmp_path):
+    """Converter.cpp's sequence through the host mirror: Convert(manifest), Save(file)."""
+    import admm_amd as A
+    V, E, k = 5, 6, 2
+    rng = np.random.default_rng(3)
+    el = rng.integers(0, V, size=(E, 2)).astype(np.int32)
+    un = rng.standard_normal((V, k)).astype(np.float32)
+    pw = rng.standard_normal((E, k * k)).astype(np.float32)
+    (tmp_path / "info.txt").write_text("%d %d %d\n" % (V, E, k))
+    el.tofile(tmp_path / "edges.bin"); un.tofile(tmp_path / "node.bin"); pw.tofile(tmp_path / "edge.bin")
+    manifest = tmp_path / "m.txt"
+    manifest.write_text("\n".join(str(tmp_path / n) for n in ["info.txt", "edges.bin", "node.bin", "edge.bin"]) + "\n")
+    g = A.Grid()
+    g.Convert(manifest)
+    out = tmp_path / "out.nc"
+    g.Save(out)
+    assert np.array_equal(GF.read_edges(out), el)
+    assert np.array_equal(GF.read_unaries(out, negate=False), un)
+    assert np.array_equal(GF.read_pairwise(out, negate=False), pw)
+    info = GF.read_info(out)
+    assert (info.rows, info.cols, info.num_vertices, info.num_edges) == (-1, -1, V, E)
