@@ -69,6 +69,12 @@ struct admm_ctx {
   // With one strip the column-side pointers alias the row-side ones.
   float *th_r = nullptr, *lam_r = nullptr;
   float *th_c = nullptr, *lam_c = nullptr;
+  // One strip (the whole grid on this device): the multipliers of the column
+  // copies are those of the row copies negated, bit for bit (opposite
+  // increments from a common zero), so only lam_r is kept; the column chains
+  // read it with the sign flipped and store nothing, and the row chains write
+  // their update into lam_c, which is swapped with lam_r after the sweep.
+  bool lam_shared() const { return d.nranks == 1; }
   int *xrow_r = nullptr;   // [batch][nrows][cols]   labels of my row chains
   int *xcolT_r = nullptr;  // [batch][cols][nrows]   column-chain labels on my rows
   int *xrow_c = nullptr;   // [rows][ncols]          row-chain labels on my columns
@@ -78,6 +84,9 @@ struct admm_ctx {
   uint8_t *bp_r = nullptr, *bp_c = nullptr;
   float *d_W = nullptr, *d_Wsplit = nullptr, *d_Wt = nullptr;
   float *d_WsplitT = nullptr, *d_WtT = nullptr;  // transposes, for the half chains swept backwards
+  // the table the sweep runs on (Wt) has a zero diagonal and one non-negative
+  // value everywhere else: the sweep kernel specialised for that form applies
+  bool potts = false;
   float *d_chain_min = nullptr;
   // The linear objective of a solve has two per-chain terms: the pairwise one
   // is written by that solve's sweep, the unary one by the NEXT sweep (which
@@ -194,8 +203,23 @@ void launch_sweep_t(const ChainArgs &a, int blocks, hipStream_t s) {
   hipLaunchKernelGGL((chain_sweep_kernel<KP, NS, GPB, MINW, DUAL>), dim3(blocks), dim3(kChainBlock), 0, s, a);
 }
 
+template <int KP>
+void launch_sweep_potts_t(const ChainArgs &a, int blocks, hipStream_t s) {
+  // a step needs few registers: four wavefronts per SIMD, operands fetched 8 steps ahead
+  // (16 ahead changes nothing: the kernel moves its bytes at the rate a streaming kernel does)
+  hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+}
+
+// ADMM_SWEEP_POTTS=0 (tuning and test knob) keeps the general kernel on a Potts table.
+bool potts_enabled() {
+  const char *e = getenv("ADMM_SWEEP_POTTS");
+  return !(e && atoi(e) == 0);
+}
+
 template <bool DUAL>
 int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
+  const bool potts = !DUAL && c->potts && potts_enabled();
+  if (potts) sh.NS = 1;  // a label's message stays in its one lane
   const int CPW = 64 / (sh.KP * sh.NS);
   int w = 0;
   for (int i = 0; i < a.nseg; i++) {
@@ -206,6 +230,19 @@ int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
   if (w == 0) return ADMM_OK;
   const int blocks = (w + kChainBlock / 64 - 1) / (kChainBlock / 64);
   hipStream_t s = c->stream;
+  if (potts) {
+    switch (sh.KP) {
+      case 2: launch_sweep_potts_t<2>(a, blocks, s); break;
+      case 4: launch_sweep_potts_t<4>(a, blocks, s); break;
+      case 8: launch_sweep_potts_t<8>(a, blocks, s); break;
+      case 16: launch_sweep_potts_t<16>(a, blocks, s); break;
+      case 32: launch_sweep_potts_t<32>(a, blocks, s); break;
+      case 64: launch_sweep_potts_t<64>(a, blocks, s); break;
+      default: return fail(c, ADMM_E_ARG, "no sweep kernel for KP=%d", sh.KP);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return ADMM_OK;
+  }
 #define SWEEP_CASE(kp, ns) \
   if (sh.KP == kp && sh.NS == ns) { launch_sweep_t<kp, ns, DUAL>(a, blocks, s); goto launched; }
   SWEEP_CASE(2, 1) SWEEP_CASE(2, 2)
@@ -223,7 +260,9 @@ launched:
 
 void fill_seg_rows(const admm_ctx *c, ChainSeg &s, bool dual) {
   const admm_desc &d = c->d;
-  s.theta = c->th_r; s.lam = c->lam_r; s.x = c->xrow_r; s.xo = c->xo_r; s.bp = c->bp_r;
+  s.theta = c->th_r; s.lam = c->lam_r; s.x = c->xrow_r;
+  s.lam_out = dual ? nullptr : (c->lam_shared() ? c->lam_c : c->lam_r);
+  s.lam_sign = 0; s.xo = c->xo_r; s.bp = c->bp_r;
   s.chain_min = dual ? c->d_chain_min : nullptr;
   s.chain_lin = c->d_chain_lin;
   s.chain_unary = c->d_chain_unary;
@@ -237,7 +276,9 @@ void fill_seg_rows(const admm_ctx *c, ChainSeg &s, bool dual) {
 
 void fill_seg_cols(const admm_ctx *c, ChainSeg &s, bool dual) {
   const admm_desc &d = c->d;
-  s.theta = c->th_c; s.lam = c->lam_c; s.x = c->xcolT_c; s.xo = c->xo_c; s.bp = c->bp_c;
+  s.theta = c->th_c; s.lam = c->lam_shared() ? c->lam_r : c->lam_c; s.x = c->xcolT_c;
+  s.lam_out = (dual || c->lam_shared()) ? nullptr : c->lam_c;
+  s.lam_sign = c->lam_shared() ? 0x80000000u : 0u; s.xo = c->xo_c; s.bp = c->bp_c;
   s.chain_min = dual ? c->d_chain_min + (long long)d.batch * c->st.nrows : nullptr;
   s.chain_lin = c->d_chain_lin + 2LL * d.batch * c->st.nrows;
   s.chain_unary = c->d_chain_unary + 2LL * d.batch * c->st.nrows;
@@ -249,7 +290,16 @@ void fill_seg_cols(const admm_ctx *c, ChainSeg &s, bool dual) {
   s.sstride = c->st.ncols;
 }
 
+int chain_sweep_launch(admm_ctx *c, bool dual);
+
 int chain_sweep(admm_ctx *c, bool dual) {
+  const int rc = chain_sweep_launch(c, dual);
+  // the row chains wrote the updated multipliers into the other buffer
+  if (!rc && !dual && c->lam_shared()) std::swap(c->lam_r, c->lam_c);
+  return rc;
+}
+
+int chain_sweep_launch(admm_ctx *c, bool dual) {
   ChainArgs a{};
   a.nseg = 2;
   fill_seg_rows(c, a.seg[0], dual);
@@ -872,6 +922,14 @@ int admm_init(admm_ctx *c) {
     }
     hipLaunchKernelGGL(chain_init_w_kernel, dim3((d.k * d.k + 255) / 256), dim3(256), 0, s, c->d_Wsplit, c->d_Wt, c->d_WsplitT, c->d_WtT, c->d_W, d.k, d.rho);
     HIP_TRY(c, hipGetLastError());
+    // Potts form of the table the sweep adds (checked on the device's own values)
+    std::vector<float> wt((size_t)d.k * d.k);
+    HIP_TRY(c, hipMemcpyAsync(wt.data(), c->d_Wt, sizeof(float) * wt.size(), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    bool potts = d.k >= 2 && wt[1] >= 0.0f;
+    for (int a = 0; a < d.k && potts; a++)
+      for (int b = 0; b < d.k && potts; b++) potts = (a == b) ? wt[(size_t)a * d.k + b] == 0.0f : wt[(size_t)a * d.k + b] == wt[1];
+    c->potts = potts;
   }
   HIP_TRY(c, hipStreamSynchronize(s));
   c->inited = true;
@@ -1644,7 +1702,7 @@ int admm_download_state(admm_ctx *c, int which, float *out) {
   } else {
     switch (which) {
       case 10: src = c->lam_r; break;
-      case 11: src = c->lam_c; break;
+      case 11: src = c->lam_shared() ? c->lam_r : c->lam_c; break;
       case 12: src = c->th_r; break;
       case 13: src = c->xrow_r; break;
       case 14:
@@ -1660,6 +1718,10 @@ int admm_download_state(admm_ctx *c, int which, float *out) {
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   if (tmp) (void)hipFree(tmp);
   HIP_TRY(c, e);
+  // the column multipliers are kept as the row ones negated (never -0: a sum
+  // that starts from +0 cannot round to it, so 0 - x restores the exact bits)
+  if (is_chain(c) && which == 11 && c->lam_shared())
+    for (size_t i = 0; i < n; i++) out[i] = 0.0f - out[i];
   return ADMM_OK;
 }
 

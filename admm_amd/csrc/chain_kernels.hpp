@@ -44,7 +44,13 @@ namespace admm {
 // contiguous in x (chain-major).
 struct ChainSeg {
   const float *theta;  // per-copy share of the unaries
-  float *lam;          // Lagrange multipliers of these chains
+  const float *lam;    // Lagrange multipliers of these chains, as read ...
+  float *lam_out;      // ... and where the updated ones go (may be lam itself); null: not stored
+  unsigned lam_sign;   // 0, or 0x80000000: lam holds the multipliers negated.  The two copies of a node
+                       // get opposite increments (mu_row - m = -(mu_col - m)), so starting from zero the
+                       // column multipliers are the row ones negated, bit for bit; on one device the
+                       // column chains read the row chains' array and store nothing, and the row chains
+                       // write into a second buffer that becomes current after the sweep.
   int *x;              // [nchains][T] labels of these chains (-1 before the first solve)
   const int *xo;       // [nchains][T] labels the crossing chains gave the same nodes
   uint8_t *bp;         // [nchains][2][half length padded to 64][KP] back-pointer scratch
@@ -196,6 +202,37 @@ __device__ __forceinline__ int first_equal4_vals(const float *c, const float bes
   return idx;
 }
 
+// Minimum of x over each aligned group of W lanes, in every lane of the group.
+// Butterfly on the cross-lane data path: quad swaps, the two row mirrors, then
+// the row and half swaps.  (Mirrors instead of xor 4 and xor 8: once the groups
+// of 4, of 8, hold one value any partner from the other group will do.)
+// Written out because the compiler cannot see that the bits a cross-lane move
+// returns are ordinary floats and quiets them before every minimum; the s_nop
+// are the two wait states between a vector write and a cross-lane read of the
+// same register, which nothing inserts inside an asm statement.
+template <int W>
+__device__ __forceinline__ float chain_lanes_min(float x) {
+  static_assert(W == 2 || W == 4 || W == 8 || W == 16 || W == 32 || W == 64, "group of lanes");
+  float r;
+  asm("s_nop 1\n\tv_min_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
+  if constexpr (W >= 4) asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(r));
+  if constexpr (W >= 8) asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(r));
+  if constexpr (W >= 16) asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(r));
+  if constexpr (W >= 32) {
+    float t;
+    asm("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_min_f32_e32 %0, %0, %1" : "+v"(r), "=&v"(t));
+  }
+  if constexpr (W >= 64) {
+    float t;
+    asm("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_min_f32_e32 %0, %0, %1" : "+v"(r), "=&v"(t));
+  }
+  return r;
+}
+
+// Lowest bit of every W-bit field of a 64-bit lane mask.
+template <int W>
+constexpr unsigned long long kFieldLsb = W >= 64 ? 1ull : (~0ull / ((1ull << (W & 63)) - 1));
+
 // KP   : labels padded to a power of two (lanes b >= k idle with M = +inf)
 // NS   : lanes that share one target label; lane s of them scans the source
 //        labels [s*KP/NS, (s+1)*KP/NS) and holds the node operands of the
@@ -210,8 +247,9 @@ __device__ __forceinline__ int first_equal4_vals(const float *c, const float bes
 // straight from registers, dword (t/4)*KP + b of the half chain's scratch;
 // the backtrack streams them back one 64-step chunk at a time (t counts the
 // steps of the half chain in sweep order).
-template <int KP, int NS, int GPB, int MINW, bool DUAL>
+template <int KP, int NS, int GPB, int MINW, bool DUAL, bool POTTS = false>
 __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const ChainArgs args) {
+  static_assert(!POTTS || (NS == 1 && !DUAL), "the Potts step keeps a label's message in its one lane");
   constexpr int LPC = KP * NS;   // lanes per chain
   constexpr int CPW = 64 / LPC;  // chains per wavefront
   constexpr int A = KP / NS;     // source labels scanned per lane
@@ -229,11 +267,11 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // messages of a step must then outlive the step: two alternating rows.
   // (tried for the split k = 32 kernel too, 16 candidates per lane: slower, its
   // single wavefront per SIMD feels the extra LDS traffic)
-  constexpr bool RECOMP = !DUAL && NS == 1 && A >= 32;
+  constexpr bool RECOMP = !POTTS && !DUAL && NS == 1 && A >= 32;
   constexpr int NG = A / 4;      // candidate groups per lane
   constexpr int NB = RECOMP ? 2 : 1;
   constexpr int WLD = KP + 4;    // padded row of the LDS pairwise table
-  constexpr bool PIPE = RECOMP || A <= 32;
+  constexpr bool PIPE = !POTTS && (RECOMP || A <= 32);
   constexpr int WPB = kChainBlock / 64;
   constexpr int MROW = CPW * KP + 64;
 
@@ -289,12 +327,31 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // pairwise column of this lane's target label, kept in registers; the
   // right half runs on the transposed table (source = label of the later node)
   const float *__restrict__ Wuse = rev ? args.WtT : args.Wt;
-  float Wr[A];
+  float Wr[POTTS ? 1 : A];
+  if constexpr (!POTTS) {
 #pragma unroll
-  for (int j = 0; j < A; j++) {
-    const int a = s * A + j;
-    Wr[j] = (a < k && bvalid) ? Wuse[a * k + b] : INF;
+    for (int j = 0; j < A; j++) {
+      const int a = s * A + j;
+      Wr[j] = (a < k && bvalid) ? Wuse[a * k + b] : INF;
+    }
   }
+  // Potts table (zero diagonal, one non-negative value w everywhere else; the
+  // host checks that before it picks this kernel).  Rounding is monotone, so
+  //   min_a (M[a] + W[a][b]) = min(M[b], C),  C = min_a (M[a] + w):
+  // the candidate a = b that C also covers is M[b] + w >= M[b] and cannot win.
+  // With i1 the lowest a whose M[a] + w equals C, the lowest source attaining
+  // the minimum is b when (M[b], b) < (C, i1) lexicographically, else i1 (b
+  // itself is never a lower index with candidate C than i1).  One add, one
+  // minimum over the chain's lanes and three compares replace the k-candidate
+  // scan, and the messages never leave their registers.
+  const float wpot = POTTS ? Wuse[1] : 0.0f;
+  // lanes past k: their message stays +inf (median with +inf is the maximum)
+  const float potts_pad = bvalid ? -INF : INF;
+  // the lane's chain as a field of the 64-bit lane masks, top bit left out (a
+  // count over it is then a label even if nothing compared equal)
+  const unsigned long long potts_field = (KP == 64 ? ~0ull : ((1ull << (KP & 63)) - 1) << ((cs * KP) & 63)) & ~(1ull << ((cs * KP + KP - 1) & 63));
+  const unsigned potts_flo = (unsigned)potts_field, potts_fhi = (unsigned)(potts_field >> 32);
+  float Mreg = bvalid ? 0.0f : INF;  // A_{-1}: min(0, 0 + w) = 0 makes the first step M_0 = t_0
 
   if constexpr (RECOMP) {
     // every wavefront of the block writes the whole table (same values), so
@@ -326,13 +383,15 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   const unsigned soff0 = rev ? 4u * nstride * (reach - (unsigned)(NS - 1)) : 0u;
   const long long base_el = first0 * k - (rev ? (long long)reach * nstride : 0);
   const __amdgpu_buffer_rsrc_t th_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sg.theta + base_el), 0, 0xFFFFFFFF, kRsrcWord3);
-  const __amdgpu_buffer_rsrc_t lam_rs = __builtin_amdgcn_make_buffer_rsrc(sg.lam + base_el, 0, 0xFFFFFFFF, kRsrcWord3);
+  const __amdgpu_buffer_rsrc_t lam_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sg.lam + base_el), 0, 0xFFFFFFFF, kRsrcWord3);
+  const __amdgpu_buffer_rsrc_t lamo_rs = __builtin_amdgcn_make_buffer_rsrc((sg.lam_out ? sg.lam_out : const_cast<float *>(sg.lam)) + base_el, 0, 0xFFFFFFFF, kRsrcWord3);
+  const unsigned lam_sign = sg.lam_sign;
   // the lane's own step of group 0, in bytes
   const unsigned lane_off = 4u * ((unsigned)((first - first0) * k) + (unsigned)(rev ? NS - 1 - s : s) * nstride + (unsigned)b);
   // Stores of lanes that own no label (padding past k, the duplicate of a
   // clamped chain) get an offset beyond the descriptor's range, which the
   // hardware drops: no branch around the store.
-  const unsigned lane_off_st = lvalid ? lane_off : 0xFFFFFFFFu;
+  const unsigned lane_off_st = (lvalid && sg.lam_out) ? lane_off : 0xFFFFFFFFu;
   auto buf_load = [&](const __amdgpu_buffer_rsrc_t &r, unsigned soff) -> float {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_off, soff, 0));
   };
@@ -396,6 +455,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // 4 * group + the lane's first source + the chain's first lane: the message
   // index of the group's first candidate, and the lane that holds that source
   int grp_pend = 0;
+  int potts_arg = 0;  // Potts step: the byte to store, worked out in the step itself
   float best_pend = 0.0f, blo_pend = 0.0f, bhi_pend = 0.0f;
   const int g_lo = cs * LPC + s * A, g_hi = g_lo + 4 * (NG / 2);
   const int g_val[4] = {g_lo, g_lo + 4, g_lo + 8, g_lo + 12};  // four groups per lane: picked directly
@@ -422,7 +482,9 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     if (DUAL) return;
     int arg = 0;
     if (live) {
-      if constexpr (RECOMP) {
+      if constexpr (POTTS) {
+        arg = potts_arg;
+      } else if constexpr (RECOMP) {
         const f4_t c4 = m4_pend + w4_pend;
         const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
         arg = grp_pend | first_equal<4>(cc, best_pend);  // the lane that holds the source label
@@ -458,7 +520,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     // With one or two chains per wavefront the byte stored is the LANE that
     // holds the source label (label + chain slot * lanes per chain): the
     // backtrack then uses it as a v_readlane selector as it stands.
-    if constexpr (CPW <= 2 && !RECOMP) arg += cs * LPC;
+    if constexpr (CPW <= 2 && !RECOMP && !POTTS) arg += cs * LPC;
     acc = __builtin_amdgcn_alignbit((unsigned)arg, acc, 8);
     if ((SBP & 3) == 3) {
       if (s == ((SBP >> 2) % NS)) keep = acc;
@@ -484,7 +546,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       constexpr int j = decltype(j_c)::value;
       const int tg = tb + j * NS;
       const bool glive = FULL || tg < T;
-      const float th_in = pth[j], lam_in = plam[j];
+      const float th_in = pth[j], lam_in = __uint_as_float(__float_as_uint(plam[j]) ^ lam_sign);
       const unsigned goff = soff0 + (unsigned)tg * sstep;  // uniform
       float th_own = INF;
       if (DUAL) {
@@ -502,7 +564,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         asm("" : "+v"(th_sel));
         unary_acc += (double)th_sel;
         const float la = lam_in + p;                          // Tree.cpp:70
-        if (FULL || tg + s < T) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(la), lam_rs, lane_off_st, goff, 0);
+        if (FULL || tg + s < T) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(la), lamo_rs, lane_off_st, goff, 0);
         th_own = rho * (th_in + la) + p;                      // Tree.cpp:85-86
       }
       static_for<0, NS>([&](auto u_c) {
@@ -513,7 +575,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         // (a) this step's messages leave LDS, with the next group's labels
         //     and the operands of the group one block ahead behind them ...
         f4 mv[(A + 3) / 4];
-        if (live) {
+        if (live && !POTTS) {
           if constexpr (A % 4 == 0) {
             const f4 *mp = reinterpret_cast<const f4 *>(Mrow + (RECOMP ? ((j * NS + u) & 1) * MROW : 0) + s * A);
 #pragma unroll
@@ -534,7 +596,8 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         }
         // memory instructions stay where they are written; with one wavefront
         // per SIMD (a split chain) letting ALU work cross pays, with two it does not
-        if constexpr (NS > 1) __builtin_amdgcn_sched_barrier(0x6);
+        if constexpr (POTTS) __builtin_amdgcn_sched_barrier(0);  // every step issues its own prefetch
+        else if constexpr (NS > 1) __builtin_amdgcn_sched_barrier(0x6);
         else __builtin_amdgcn_sched_barrier(0);
         // (b) ... while the previous step's back-pointer is worked out
         if constexpr (RECOMP) {
@@ -555,7 +618,26 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
           __builtin_amdgcn_sched_barrier(0);
         }
         // (c) min-plus of this step
-        if (live) {
+        if constexpr (POTTS) {
+          if (live) {
+            const float c = Mreg + wpot;
+            const float C1 = chain_lanes_min<KP>(c);
+            const unsigned long long eq = __builtin_amdgcn_ballot_w64(c == C1);
+            const unsigned long long lt = __builtin_amdgcn_ballot_w64(Mreg < C1);
+            const unsigned long long le = __builtin_amdgcn_ballot_w64(Mreg <= C1);
+            // lanes below the chain's lowest lane with c == C1 (every chain's
+            // field of eq has a bit set, so the borrow stays inside the field)
+            const unsigned long long below = (eq - kFieldLsb<KP>) & ~eq;
+            const unsigned long long keepm = lt | (le & below);
+            // i1 = number of lanes below it, plus the chain's first lane when the
+            // byte stored is a lane
+            const int i1 = __builtin_popcount((unsigned)below & potts_flo) + __builtin_popcount((unsigned)(below >> 32) & potts_fhi) +
+                           (CPW <= 2 ? cs * LPC : 0);
+            const int self = CPW <= 2 ? lane : b;
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(potts_arg) : "v"(i1), "v"(self), "s"(keepm));
+            Mreg = th_own + __builtin_amdgcn_fmed3f(Mreg, C1, potts_pad);
+          }
+        } else if (live) {
           float c[A];
           if constexpr (A % 4 == 0) {
 #pragma unroll
@@ -663,6 +745,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // and hands the left half its last label.  Every wavefront of the
   // workgroup passes the same two barriers (one that has already returned is
   // not waited for).
+  if constexpr (POTTS) Mrow[b] = Mreg;
   wave_lds_fence();
   const float *Mlast = Mrow + (RECOMP ? (T & 1) * MROW : 0);  // step T-1 wrote row T & 1
   float bv = Mlast[b];
@@ -690,7 +773,10 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     int garg = 0;
 #pragma unroll
     for (int j = 0; j < A; j++) {
-      const float cnd = Mlast[s * A + j] + Wr[j];
+      float wj;
+      if constexpr (POTTS) wj = (j < k && bvalid) ? (j == b ? 0.0f : wpot) : INF;
+      else wj = Wr[j];
+      const float cnd = Mlast[s * A + j] + wj;
       if (cnd < gbest) { gbest = cnd; garg = s * A + j; }
     }
 #pragma unroll

@@ -1,0 +1,169 @@
+// Memory-rate probe for the chain sweep's access patterns on one GPU: what rate do two
+// streamed reads and one streamed write reach when they are issued the way the sweep
+// issues them (one node = 128 B per chain and step), against a plain streaming kernel?
+//   hipcc --offload-arch=gfx950 -O3 -o access_patterns tools/access_patterns.hip && ./access_patterns
+// Prints one line per pattern: bytes moved, milliseconds, TB/s.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x)                                                                       \
+  do {                                                                              \
+    hipError_t e_ = (x);                                                            \
+    if (e_ != hipSuccess) {                                                         \
+      fprintf(stderr, "%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__);   \
+      exit(1);                                                                      \
+    }                                                                               \
+  } while (0)
+
+constexpr int R = 2048, C = 2048, K = 32;  // nodes of 32 floats, row-major
+constexpr long long N = (long long)R * C * K;
+
+// plain streaming: lam[i] = th[i] + lam[i], 16 B per lane
+__global__ __launch_bounds__(256) void stream_kernel(const float4 *__restrict__ th, float4 *__restrict__ lam, long long n4) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 a = th[i], b = lam[i];
+    lam[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+}
+
+// The sweep's pattern.  A wavefront walks two chains, half a chain each way as the sweep
+// does (left half forwards, right half backwards), one node (32 lanes x 4 B) per chain and
+// step, operands fetched D steps ahead.  COL = false: chains are rows (a step advances 128 B,
+// the two chains lie 256 KiB apart); COL = true: chains are columns (a step advances a whole
+// row, the two chains are adjacent).  WRITE = false leaves out the store.
+template <bool COL, int D, bool WRITE>
+__global__ __launch_bounds__(256) void walk_kernel(const float *__restrict__ th, float *__restrict__ lam, float *__restrict__ sink) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int rev = wave & 1;
+  const int chain = (wave >> 1) * 2 + (lane >> 5);
+  const int T = (COL ? R : C) / 2;
+  const long long step = COL ? (long long)C * K : K;
+  const long long base = (COL ? (long long)chain * K : (long long)chain * C * K) + (lane & 31);
+  long long pos = rev ? base + (2LL * T - 1) * step : base;
+  const long long dir = rev ? -step : step;
+  float a[D], b[D];
+#pragma unroll
+  for (int j = 0; j < D; j++) {
+    a[j] = th[pos + j * dir];
+    b[j] = lam[pos + j * dir];
+  }
+  float acc = 0.f;
+  for (int t = 0; t < T; t += D) {
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+      const float v = a[j] + b[j];
+      acc += v;
+      if (WRITE) lam[pos + j * dir] = v;
+      if (t + D < T) {
+        a[j] = th[pos + (j + D) * dir];
+        b[j] = lam[pos + (j + D) * dir];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    pos += D * dir;
+  }
+  if (acc == 123.456f) sink[0] = acc;
+}
+
+// Rows again, 16 B per lane: a wavefront load covers four consecutive nodes of each of its
+// two chains (512 B contiguous per chain), fetched D groups ahead.
+template <int D, bool WRITE>
+__global__ __launch_bounds__(256) void walk_rows_x4_kernel(const float4 *__restrict__ th, float4 *__restrict__ lam, float *__restrict__ sink) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int rev = wave & 1;
+  const int chain = (wave >> 1) * 2 + (lane >> 5);
+  const int G = C / 2 / 4;  // groups of four nodes per half chain
+  const long long step = 32;  // float4 per group
+  const long long base = (long long)chain * C * K / 4 + (lane & 31);
+  long long pos = rev ? base + (2LL * G - 1) * step : base;
+  const long long dir = rev ? -step : step;
+  float4 a[D], b[D];
+#pragma unroll
+  for (int j = 0; j < D; j++) {
+    a[j] = th[pos + j * dir];
+    b[j] = lam[pos + j * dir];
+  }
+  float acc = 0.f;
+  for (int t = 0; t < G; t += D) {
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+      const float4 v = make_float4(a[j].x + b[j].x, a[j].y + b[j].y, a[j].z + b[j].z, a[j].w + b[j].w);
+      acc += v.x + v.y + v.z + v.w;
+      if (WRITE) lam[pos + j * dir] = v;
+      if (t + D < G) {
+        a[j] = th[pos + (j + D) * dir];
+        b[j] = lam[pos + (j + D) * dir];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    pos += D * dir;
+  }
+  if (acc == 123.456f) sink[0] = acc;
+}
+
+template <typename F>
+void timeit(const char *name, double bytes, F launch) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; i++) launch();
+  CK(hipDeviceSynchronize());
+  const int reps = 20;
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < reps; i++) launch();
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  printf("%-44s %8.3f GB  %7.3f ms  %6.2f TB/s\n", name, bytes / 1e9, ms, bytes / ms / 1e9);
+  fflush(stdout);
+}
+
+int main() {
+  float *th, *lam, *sink;
+  CK(hipMalloc(&th, N * sizeof(float)));
+  CK(hipMalloc(&lam, N * sizeof(float)));
+  CK(hipMalloc(&sink, 256));
+  CK(hipMemset(th, 0, N * sizeof(float)));
+  CK(hipMemset(lam, 0, N * sizeof(float)));
+  const double rd = 2.0 * N * 4, wr = 1.0 * N * 4;
+  const int rows_blocks = R / 2 * 2 / 4, cols_blocks = C / 2 * 2 / 4;  // two chains per wavefront, two halves, four wavefronts per block
+  timeit("stream 2 reads + 1 write, 16 B/lane", rd + wr, [&] {
+    hipLaunchKernelGGL(stream_kernel, dim3(256 * 16), dim3(256), 0, 0, (const float4 *)th, (float4 *)lam, N / 4);
+  });
+  timeit("rows, 4 B/lane, 8 ahead, read+write", rd + wr, [&] {
+    hipLaunchKernelGGL((walk_kernel<false, 8, true>), dim3(rows_blocks), dim3(256), 0, 0, th, lam, sink);
+  });
+  timeit("rows, 4 B/lane, 8 ahead, read only", rd, [&] {
+    hipLaunchKernelGGL((walk_kernel<false, 8, false>), dim3(rows_blocks), dim3(256), 0, 0, th, lam, sink);
+  });
+  timeit("rows, 4 B/lane, 16 ahead, read+write", rd + wr, [&] {
+    hipLaunchKernelGGL((walk_kernel<false, 16, true>), dim3(rows_blocks), dim3(256), 0, 0, th, lam, sink);
+  });
+  timeit("columns, 4 B/lane, 8 ahead, read+write", rd + wr, [&] {
+    hipLaunchKernelGGL((walk_kernel<true, 8, true>), dim3(cols_blocks), dim3(256), 0, 0, th, lam, sink);
+  });
+  timeit("columns, 4 B/lane, 8 ahead, read only", rd, [&] {
+    hipLaunchKernelGGL((walk_kernel<true, 8, false>), dim3(cols_blocks), dim3(256), 0, 0, th, lam, sink);
+  });
+  timeit("columns, 4 B/lane, 16 ahead, read+write", rd + wr, [&] {
+    hipLaunchKernelGGL((walk_kernel<true, 16, true>), dim3(cols_blocks), dim3(256), 0, 0, th, lam, sink);
+  });
+  timeit("rows, 16 B/lane, 4 groups ahead, read+write", rd + wr, [&] {
+    hipLaunchKernelGGL((walk_rows_x4_kernel<4, true>), dim3(rows_blocks), dim3(256), 0, 0, (const float4 *)th, (float4 *)lam, sink);
+  });
+  timeit("rows, 16 B/lane, 8 groups ahead, read+write", rd + wr, [&] {
+    hipLaunchKernelGGL((walk_rows_x4_kernel<8, true>), dim3(rows_blocks), dim3(256), 0, 0, (const float4 *)th, (float4 *)lam, sink);
+  });
+  timeit("rows, 16 B/lane, 4 groups ahead, read only", rd, [&] {
+    hipLaunchKernelGGL((walk_rows_x4_kernel<4, false>), dim3(rows_blocks), dim3(256), 0, 0, (const float4 *)th, (float4 *)lam, sink);
+  });
+  CK(hipDeviceSynchronize());
+  return 0;
+}
