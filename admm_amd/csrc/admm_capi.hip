@@ -218,7 +218,9 @@ bool potts_enabled() {
 
 template <bool DUAL>
 int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
-  const bool potts = !DUAL && c->potts && potts_enabled();
+  // (2 or 4 labels: the general kernel's scan is as short, and its per-chain walk does not
+  // unroll 16 or 32 chains deep)
+  const bool potts = !DUAL && c->potts && sh.KP >= 8 && potts_enabled();
   if (potts) sh.NS = 1;  // a label's message stays in its one lane
   const int CPW = 64 / (sh.KP * sh.NS);
   int w = 0;
@@ -232,8 +234,6 @@ int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
   hipStream_t s = c->stream;
   if (potts) {
     switch (sh.KP) {
-      case 2: launch_sweep_potts_t<2>(a, blocks, s); break;
-      case 4: launch_sweep_potts_t<4>(a, blocks, s); break;
       case 8: launch_sweep_potts_t<8>(a, blocks, s); break;
       case 16: launch_sweep_potts_t<16>(a, blocks, s); break;
       case 32: launch_sweep_potts_t<32>(a, blocks, s); break;
@@ -662,8 +662,10 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
         (rc = dev_alloc(c, &c->lam_c, ncol_nodes * k + 2 * slack)) ||
         (rc = dev_alloc(c, &c->xrow_r, nrow_nodes)) || (rc = dev_alloc(c, &c->xcolT_c, ncol_nodes)) ||
         (rc = dev_alloc(c, &c->xo_r, nrow_nodes)) || (rc = dev_alloc(c, &c->xo_c, ncol_nodes)) ||
-        (rc = dev_alloc(c, &c->bp_r, B * c->st.nrows * Tp_r * c->KP + 16)) ||
-        (rc = dev_alloc(c, &c->bp_c, B * c->st.ncols * Tp_c * c->KP + 16)) ||
+        // (+ 16 bytes per step: the Potts kernel's layout is per wavefront, and its last
+        // wavefront may hold a single chain of 8 labels)
+        (rc = dev_alloc(c, &c->bp_r, B * c->st.nrows * Tp_r * c->KP + 16 * Tp_r + 16)) ||
+        (rc = dev_alloc(c, &c->bp_c, B * c->st.ncols * Tp_c * c->KP + 16 * Tp_c + 16)) ||
         (rc = dev_alloc(c, &c->d_W, k * k)) || (rc = dev_alloc(c, &c->d_Wsplit, k * k)) ||
         (rc = dev_alloc(c, &c->d_Wt, k * k)) || (rc = dev_alloc(c, &c->d_WsplitT, k * k)) ||
         (rc = dev_alloc(c, &c->d_WtT, k * k)) ||

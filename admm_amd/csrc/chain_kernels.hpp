@@ -347,10 +347,12 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   const float wpot = POTTS ? Wuse[1] : 0.0f;
   // lanes past k: their message stays +inf (median with +inf is the maximum)
   const float potts_pad = bvalid ? -INF : INF;
-  // the lane's chain as a field of the 64-bit lane masks, top bit left out (a
-  // count over it is then a label even if nothing compared equal)
-  const unsigned long long potts_field = (KP == 64 ? ~0ull : ((1ull << (KP & 63)) - 1) << ((cs * KP) & 63)) & ~(1ull << ((cs * KP + KP - 1) & 63));
-  const unsigned potts_flo = (unsigned)potts_field, potts_fhi = (unsigned)(potts_field >> 32);
+  // Back-pointers of the Potts step: two lane masks per step, keep (the
+  // minimum for target b is attained by b itself first) and eq (lanes whose
+  // M + w equals the chain's C; the lowest one of a chain's field is i1).  Step
+  // tt of a 64-step chunk goes to lane tt of four registers, which are stored
+  // once per chunk: 16 bytes per step and wavefront instead of one per label.
+  int vk0 = 0, vk1 = 0, ve0 = 0, ve1 = 0;
   float Mreg = bvalid ? 0.0f : INF;  // A_{-1}: min(0, 0 + w) = 0 makes the first step M_0 = t_0
 
   if constexpr (RECOMP) {
@@ -401,6 +403,8 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   const int Tpad = (T + kChunk - 1) / kChunk * kChunk;
   const int TpadH = (Lhalf + kChunk - 1) / kChunk * kChunk;  // scratch per half chain, in steps
   uint32_t *bpchain = DUAL ? nullptr : reinterpret_cast<uint32_t *>(sg.bp) + ((long long)chain * 2 + rev) * (TpadH / 4) * KP;
+  // Potts step: the wavefront's share of the scratch, [half][chunk][4][64] dwords
+  uint32_t *bpwave = DUAL ? nullptr : reinterpret_cast<uint32_t *>(sg.bp) + (long long)chain0 * 2 * (TpadH / 4) * KP + (long long)rev * 4 * TpadH;
   // the same scratch for the stores of the forward pass: descriptor at the
   // wavefront's first chain, the lane's chain and label as a fixed offset
   const __amdgpu_buffer_rsrc_t bp_rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -455,7 +459,6 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // 4 * group + the lane's first source + the chain's first lane: the message
   // index of the group's first candidate, and the lane that holds that source
   int grp_pend = 0;
-  int potts_arg = 0;  // Potts step: the byte to store, worked out in the step itself
   float best_pend = 0.0f, blo_pend = 0.0f, bhi_pend = 0.0f;
   const int g_lo = cs * LPC + s * A, g_hi = g_lo + 4 * (NG / 2);
   const int g_val[4] = {g_lo, g_lo + 4, g_lo + 8, g_lo + 12};  // four groups per lane: picked directly
@@ -482,9 +485,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     if (DUAL) return;
     int arg = 0;
     if (live) {
-      if constexpr (POTTS) {
-        arg = potts_arg;
-      } else if constexpr (RECOMP) {
+      if constexpr (RECOMP) {
         const f4_t c4 = m4_pend + w4_pend;
         const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
         arg = grp_pend | first_equal<4>(cc, best_pend);  // the lane that holds the source label
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     // With one or two chains per wavefront the byte stored is the LANE that
     // holds the source label (label + chain slot * lanes per chain): the
     // backtrack then uses it as a v_readlane selector as it stands.
-    if constexpr (CPW <= 2 && !RECOMP && !POTTS) arg += cs * LPC;
+    if constexpr (CPW <= 2 && !RECOMP) arg += cs * LPC;
     acc = __builtin_amdgcn_alignbit((unsigned)arg, acc, 8);
     if ((SBP & 3) == 3) {
       if (s == ((SBP >> 2) % NS)) keep = acc;
@@ -629,12 +630,16 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
             // field of eq has a bit set, so the borrow stays inside the field)
             const unsigned long long below = (eq - kFieldLsb<KP>) & ~eq;
             const unsigned long long keepm = lt | (le & below);
-            // i1 = number of lanes below it, plus the chain's first lane when the
-            // byte stored is a lane
-            const int i1 = __builtin_popcount((unsigned)below & potts_flo) + __builtin_popcount((unsigned)(below >> 32) & potts_fhi) +
-                           (CPW <= 2 ? cs * LPC : 0);
-            const int self = CPW <= 2 ? lane : b;
-            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(potts_arg) : "v"(i1), "v"(self), "s"(keepm));
+            const int ls = tt0 + j;  // the step's place in its chunk (uniform)
+            // into lane ls of the four registers: moves with only that lane enabled (a
+            // lane write takes one scalar operand, and the lane would be a second)
+            // (s_bfm: one set bit at the offset, and unlike a shift it leaves the
+            // scalar condition code alone)
+            asm("s_bfm_b64 exec, 1, %8\n\t"
+                "v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7\n\t"
+                "s_mov_b64 exec, -1"
+                : "+v"(vk0), "+v"(vk1), "+v"(ve0), "+v"(ve1)
+                : "s"((unsigned)keepm), "s"((unsigned)(keepm >> 32)), "s"((unsigned)eq), "s"((unsigned)(eq >> 32)), "s"(ls));
             Mreg = th_own + __builtin_amdgcn_fmed3f(Mreg, C1, potts_pad);
           }
         } else if (live) {
@@ -692,7 +697,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
           s_M[wib][(RECOMP ? (((j * NS + u) & 1) ^ 1) * MROW : 0) + m_addr[u]] = Mnew;
           wave_lds_fence();
         }
-        if constexpr (!PIPE) finish(std::integral_constant<int, j * NS + u>{}, tb, live);
+        if constexpr (!PIPE && !POTTS) finish(std::integral_constant<int, j * NS + u>{}, tb, live);
       });
     });
   };
@@ -712,6 +717,10 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     } else {
 #pragma unroll 1
       for (int tt = 0; tt < kChunk && t0 + tt < T; tt += BLK) block(t0 + tt, tt, std::false_type{});  // tail
+    }
+    if constexpr (POTTS) {
+      uint32_t *o = bpwave + (t0 / kChunk) * 256 + lane;
+      o[0] = (uint32_t)vk0; o[64] = (uint32_t)vk1; o[128] = (uint32_t)ve0; o[192] = (uint32_t)ve1;
     }
     if (!DUAL && t0 + kChunk < T) {
       wave_lds_fence();
@@ -822,6 +831,134 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // copy while the chunk before it is already being fetched into registers
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // this wavefront's own back-pointer stores
   const int nchunks = Tpad / kChunk;
+  if constexpr (POTTS) {
+    // Lane tt holds the two masks of step tt of the chunk; the walk runs on the
+    // scalar unit: x_{t-1} = x_t when bit x_t of the chain's field of keep is set,
+    // else the lowest set bit of the chain's field of eq.  Labels are collected
+    // in one register per chain (lane tt = step tt of the chunk).
+    uint32_t mr[4], mn[4], mf[4];  // this chunk, the next one, in flight
+    auto load_chunk = [&](uint32_t (&dst)[4], int ci) {
+      const uint32_t *src = bpwave + (long long)ci * 256 + lane;
+#pragma unroll
+      for (int i = 0; i < 4; i++) dst[i] = src[i * 64];
+    };
+    int curs[CPW], carry[CPW];
+    double linc[CPW];
+    float wp[CPW];
+    int *xcb[CPW];  // uniform base pointers of the chains of this wavefront
+    bool cval[CPW];
+#pragma unroll
+    for (int q = 0; q < CPW; q++) {
+      curs[q] = __builtin_amdgcn_readlane(bi, q * LPC);       // the chain's last label
+      carry[q] = __builtin_amdgcn_readlane(xjoin, q * LPC);   // used by the right half only
+      linc[q] = 0.0;
+      wp[q] = 0.0f;
+      const int craw = (wlocal >> 1) * CPW + q;
+      cval[q] = craw < sg.nchains;
+      const int cq = cval[q] ? craw : sg.nchains - 1;
+      xcb[q] = sg.x + (long long)cq * Tfull + (rev ? Tfull - 1 : 0);
+    }
+    load_chunk(mr, nchunks - 1);
+    if (nchunks > 1) load_chunk(mn, nchunks - 2);
+    for (int ci = nchunks - 1; ci >= 0; ci--) {
+      const int t0 = ci * kChunk;
+      const int n = min(kChunk, T - t0);
+      if (ci > 1) load_chunk(mf, ci - 2);
+      __builtin_amdgcn_sched_barrier(0);
+      int xr[CPW];
+#pragma unroll
+      for (int q = 0; q < CPW; q++) xr[q] = 0;
+      auto walk_step = [&](auto tt_c) {
+        constexpr int tt = decltype(tt_c)::value;
+        const unsigned long long keepm = (unsigned)__builtin_amdgcn_readlane((int)mr[0], tt) |
+                                         ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mr[1], tt) << 32);
+        const unsigned long long eqm = (unsigned)__builtin_amdgcn_readlane((int)mr[2], tt) |
+                                       ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mr[3], tt) << 32);
+#pragma unroll
+        for (int q = 0; q < CPW; q++) {
+          const int cu = __builtin_amdgcn_readfirstlane(curs[q]);  // already uniform: keeps it scalar
+          asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(xr[q]) : "s"(cu), "n"(tt));
+          // at the chain's first node the masks are not used (whatever they hold
+          // gives a label below KP)
+          const int i1 = __builtin_ctzll((eqm >> (q * KP)) | (1ull << (KP - 1))) & (KP - 1);
+          curs[q] = ((keepm >> (q * KP + cu)) & 1) ? cu : i1;
+        }
+      };
+      if (n == kChunk && CPW == 2) {
+        // Two chains of 32 labels, one per half of the masks.  i1 of all 64
+        // steps at once (one vector instruction per chain), then per step and
+        // chain: record the label, test its bit of keep, keep it or take i1.
+        // Hand-written so that the walk costs the scalar unit two instructions
+        // per chain and step (it issues one per four cycles and SIMD, and that,
+        // not latency, is what the walk of four wavefronts per SIMD runs into).
+        const int vi0 = __builtin_ctz(mr[2] | 0x80000000u), vi1 = __builtin_ctz(mr[3] | 0x80000000u);
+#pragma unroll
+        for (int q = 0; q < CPW; q++) curs[q] = __builtin_amdgcn_readfirstlane(curs[q]);  // uniform already; pins it to a scalar register
+        asm volatile("s_nop 1");  // a vector instruction wrote the scalar the first lane write reads
+        static_for<0, kChunk>([&](auto r_c) {
+          constexpr int tt = kChunk - 1 - decltype(r_c)::value;
+          // named references: operands of an asm statement alone do not make
+          // a generic lambda capture a variable
+          int &x0 = xr[0], &x1 = xr[CPW - 1], &c0 = curs[0], &c1 = curs[CPW - 1];
+          int k0, k1, j0, j1;
+          const uint32_t m0 = mr[0], m1 = mr[1];
+          const int i0v = vi0, i1v = vi1;
+          asm volatile(
+              "v_readlane_b32 %[k0], %[m0], %[tt]\n\tv_readlane_b32 %[k1], %[m1], %[tt]\n\t"
+              "v_readlane_b32 %[j0], %[i0], %[tt]\n\tv_readlane_b32 %[j1], %[i1], %[tt]\n\t"
+              "v_writelane_b32 %[x0], %[c0], %[tt]\n\tv_writelane_b32 %[x1], %[c1], %[tt]\n\t"
+              "s_bitcmp1_b32 %[k0], %[c0]\n\ts_cselect_b32 %[c0], %[c0], %[j0]\n\t"
+              "s_bitcmp1_b32 %[k1], %[c1]\n\ts_cselect_b32 %[c1], %[c1], %[j1]"
+              : [x0] "+v"(x0), [x1] "+v"(x1), [c0] "+s"(c0), [c1] "+s"(c1), [k0] "=&s"(k0), [k1] "=&s"(k1), [j0] "=&s"(j0), [j1] "=&s"(j1)
+              : [m0] "v"(m0), [m1] "v"(m1), [i0] "v"(i0v), [i1] "v"(i1v), [tt] "n"(tt)
+              : "scc");
+        });
+      } else if (n == kChunk) {
+        static_for<0, kChunk>([&](auto r_c) { walk_step(std::integral_constant<int, kChunk - 1 - decltype(r_c)::value>{}); });
+      } else {
+        static_for<0, kChunk>([&](auto r_c) {
+          constexpr int tt = kChunk - 1 - decltype(r_c)::value;
+          if (tt < n) walk_step(std::integral_constant<int, tt>{});
+        });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // labels out, and this chunk's terms of the linear objective
+#pragma unroll
+      for (int q = 0; q < CPW; q++) {
+        linc[q] += (double)wp[q];
+        const int xi = xr[q];
+        int xn = __shfl_down(xi, 1);
+        xn = (lane == n - 1) ? carry[q] : xn;
+        const int t = t0 + lane;
+        if (n == kChunk && cval[q]) {
+          xcb[q][xdir * t] = xi;
+          const float wv = Wsp[xi * k + xn];
+          wp[q] = (t + 1 < Tedge) ? wv : 0.0f;
+        } else {
+          wp[q] = 0.0f;
+          if (lane < n) {
+            if (cval[q]) xcb[q][xdir * t] = xi;
+            if (t + 1 < Tedge) wp[q] = Wsp[xi * k + xn];
+          }
+        }
+        carry[q] = __builtin_amdgcn_readlane(xi, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        mr[i] = mn[i];
+        mn[i] = mf[i];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < CPW; q++) {
+      double l = linc[q] + (double)wp[q];
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) l += __shfl_xor(l, d);
+      if (cval[q] && lane == 0) sg.chain_lin[2 * ((wlocal >> 1) * CPW + q) + rev] = l;
+    }
+    if (args.stamps && lane == 0) args.stamps[3 * (size_t)wave + 2] = __builtin_readcyclecounter();
+    return;
+  }
   if constexpr (CPW <= 2) {
     // One or two chains per wavefront: the walk runs on the scalar unit.  Lane
     // b keeps its label's sixteen back-pointer dwords of the chunk in
