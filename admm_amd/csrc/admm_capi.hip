@@ -216,11 +216,17 @@ bool potts_enabled() {
   return !(e && atoi(e) == 0);
 }
 
+// 8 or 16 labels with chains to spare: the general kernel packs them as densely and walks
+// the chains of a wavefront side by side, one lane each; measured equal or slightly ahead.
+// 2 or 4 labels: the general kernel's scan is as short, and the Potts kernel's per-chain
+// walk does not unroll 16 or 32 chains deep.
+bool potts_chosen(const admm_ctx *c, SweepShape sh) {
+  return c->potts && (sh.KP >= 32 || (sh.KP >= 8 && sh.NS > 1)) && potts_enabled();
+}
+
 template <bool DUAL>
 int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
-  // (2 or 4 labels: the general kernel's scan is as short, and its per-chain walk does not
-  // unroll 16 or 32 chains deep)
-  const bool potts = !DUAL && c->potts && sh.KP >= 8 && potts_enabled();
+  const bool potts = !DUAL && potts_chosen(c, sh);
   if (potts) sh.NS = 1;  // a label's message stays in its one lane
   const int CPW = 64 / (sh.KP * sh.NS);
   int w = 0;
@@ -1755,6 +1761,20 @@ int admm_profile_reset(admm_ctx *c, int enable) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->prof = enable != 0;
   c->prof_used = 0;
+  return ADMM_OK;
+}
+
+int admm_sweep_kernel_info(admm_ctx *c, int *label_lanes, int *lanes_per_label, int *potts_out) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!is_chain(c)) return fail(c, ADMM_E_ARG, "the edge solver has no sweep kernel");
+  if (!c->inited) return fail(c, ADMM_E_STATE, "admm_sweep_kernel_info before admm_init");
+  SweepShape sh = pick_shape(c->KP, (long long)c->d.batch * ((long long)c->st.nrows + c->st.ncols));
+  const bool potts = potts_chosen(c, sh);
+  if (potts) sh.NS = 1;
+  if (label_lanes) *label_lanes = sh.KP;
+  if (lanes_per_label) *lanes_per_label = sh.NS;
+  if (potts_out) *potts_out = potts ? 1 : 0;
   return ADMM_OK;
 }
 

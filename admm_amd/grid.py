@@ -345,6 +345,12 @@ class Grid:
         self._ck(lib.admm_profile_read(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def SweepKernelInfo(self):
+        """(lanes a label vector is padded to, lanes per target label, Potts kernel chosen)."""
+        kp, ns, potts = C.c_int(), C.c_int(), C.c_int()
+        self._ck(lib.admm_sweep_kernel_info(self._h, C.byref(kp), C.byref(ns), C.byref(potts)))
+        return kp.value, ns.value, bool(potts.value)
+
     def close(self):
         if self._h:
             lib.admm_destroy(self._h)

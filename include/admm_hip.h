@@ -216,6 +216,13 @@ int admm_grid_edges(int rows, int cols, int32_t *edge_list);
 int admm_profile_reset(admm_ctx *ctx, int enable);
 int admm_profile_read(admm_ctx *ctx, double *compute_ms_avg, int *launches);
 
+/* Which sweep kernel admm_compute launches for this context (chain solver,
+ * after admm_init): lanes a label vector is padded to, lanes that share one
+ * target label, and whether the kernel specialised for Potts tables (zero
+ * diagonal, one non-negative value everywhere else) is the one chosen.  A
+ * diagnostic without a counterpart in the reference. */
+int admm_sweep_kernel_info(admm_ctx *ctx, int *label_lanes, int *lanes_per_label, int *potts);
+
 /* Number of HIP devices visible to this process (0 when there is none). */
 int admm_device_count(void);
 

@@ -1,0 +1,131 @@
+"""The sweep kernel specialised for Potts tables (zero diagonal, one non-negative value
+everywhere else) against the oracle's general min-plus recursion, and against the general
+kernel on the same inputs (ADMM_SWEEP_POTTS=0 keeps the general kernel on a Potts table).
+Bit-exact: labels of every iteration, both multiplier arrays, the three objectives."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _potts(k, w):
+    W = np.full((k, k), w, dtype=np.float32)
+    np.fill_diagonal(W, 0.0)
+    return W
+
+
+def _run_gpu(R, C, k, un, W, G, iters, potts_env):
+    import admm_amd as A
+    old = os.environ.get("ADMM_SWEEP_POTTS")
+    if potts_env is None:
+        os.environ.pop("ADMM_SWEEP_POTTS", None)
+    else:
+        os.environ["ADMM_SWEEP_POTTS"] = potts_env
+    try:
+        gs = []
+        for r in range(G):
+            g = A.Grid(rank=r, nprocs=G)
+            g.SetPartitioner(A.ROW)
+            g.SetPenalties(0.5, 1.0)
+            g.SetGlobalInfo(R, C, k)
+            g.Load(un, W)
+            g.InitOptimization()
+            gs.append(g)
+        info = [g.SweepKernelInfo() for g in gs]
+        labels = []
+        for _ in range(iters):
+            for g in gs:
+                g.Compute()
+            if G > 1:
+                A.communicate_group(gs)
+            for g in gs:
+                g.Update()
+            labels.append(np.concatenate([g.Labels().reshape(-1, C) for g in gs if g.StripInfo()[1] > 0], axis=0))
+        lam_r = np.concatenate([g.State(10).reshape(-1, C, k) for g in gs if g.StripInfo()[1] > 0], axis=0)
+        lam_c = np.concatenate([g.State(11).reshape(R, -1, k) for g in gs if g.StripInfo()[3] > 0], axis=1)
+        xrow = np.concatenate([g.State(13).reshape(-1, C) for g in gs if g.StripInfo()[1] > 0], axis=0)
+        xcol = np.concatenate([g.State(14).reshape(R, -1) for g in gs if g.StripInfo()[3] > 0], axis=1)
+        obj = (sum(g.Objective()[0] for g in gs), sum(g.Objective()[1] for g in gs), sum(g.ComputeLinearObj() for g in gs))
+        for g in gs:
+            g.close()
+        return dict(info=info, labels=labels, lam_r=lam_r, lam_c=lam_c, xrow=xrow, xcol=xcol, obj=obj)
+    finally:
+        if old is None:
+            os.environ.pop("ADMM_SWEEP_POTTS", None)
+        else:
+            os.environ["ADMM_SWEEP_POTTS"] = old
+
+
+def _check(R, C, k, un, W, G=1, iters=4, expect_potts=True):
+    from oracle import oracle as O
+    o = O.ChainOracle(R, C, k, un, W)
+    o.init()
+    ref_labels = []
+    for _ in range(iters):
+        o.compute(); o.update()
+        ref_labels.append(o.labels().copy())
+    a = _run_gpu(R, C, k, un, W, G, iters, None)
+    assert all(i[2] == expect_potts for i in a["info"]), a["info"]
+    b = _run_gpu(R, C, k, un, W, G, iters, "0")
+    assert not any(i[2] for i in b["info"]), b["info"]
+    for name, r in (("potts kernel" if expect_potts else "default kernel", a), ("general kernel", b)):
+        for it in range(iters):
+            assert np.array_equal(r["labels"][it], ref_labels[it]), "%s: labels, iteration %d" % (name, it + 1)
+        assert np.array_equal(r["xrow"], o.xrow) and np.array_equal(r["xcol"], o.xcol), name
+        assert np.array_equal(r["lam_r"], o.lambda_row), name + ": row multipliers"
+        assert np.array_equal(r["lam_c"], o.lambda_col), name + ": column multipliers"
+        assert not np.signbit(r["lam_c"][r["lam_c"] == 0]).any(), name + ": a zero multiplier came back as -0"
+        po, do, lo = o.objective()
+        for x, y in zip(r["obj"], (po, do, lo)):
+            # (an infinite weight gives an infinite primal energy once the two copies disagree)
+            assert x == y or abs(x - y) <= 1e-9 * max(abs(y), 1e-30) + 1e-12, (name, r["obj"], (po, do, lo))
+    assert a["obj"] == b["obj"]
+
+
+def _unaries(R, C, k, seed, quant=None):
+    rng = np.random.default_rng(seed)
+    un = rng.random((R * C, k), dtype=np.float32) * 4
+    if quant:
+        un = (np.floor(un * quant) / quant).astype(np.float32)  # many exact ties
+    return un
+
+
+@pytest.mark.parametrize("k", [8, 21, 32, 33, 64])
+@pytest.mark.parametrize("G", [1, 3])
+def test_potts_kernel_matches_oracle_and_general_kernel(k, G):
+    R, C = 150, 262  # half chains of 75 and 131 steps: whole 64-step chunks and tails, odd and even
+    _check(R, C, k, _unaries(R, C, k, 5 + k), _potts(k, 0.75), G=G)
+
+
+@pytest.mark.parametrize("w", [0.0, 0.25, 1e-30, 1e30, float("inf")])
+def test_potts_weights_with_ties(w):
+    # quantised unaries and a weight on the same lattice (or zero, or absorbing): ties between
+    # keeping the label and switching, and between several switch targets, in most steps
+    R, C, k = 70, 200, 32
+    _check(R, C, k, _unaries(R, C, k, 3, quant=4), _potts(k, w))
+
+
+def test_constant_unaries_all_ties():
+    R, C, k = 40, 140, 32
+    un = np.zeros((R * C, k), dtype=np.float32)
+    _check(R, C, k, un, _potts(k, 0.5))
+    _check(R, C, k, un, _potts(k, 0.0))
+
+
+def test_tables_that_are_not_potts_take_the_general_kernel():
+    R, C, k = 33, 150, 32
+    un = _unaries(R, C, k, 9, quant=8)
+    W = _potts(k, 0.5); W[3, 7] = 0.25          # one entry off
+    _check(R, C, k, un, W, expect_potts=False)
+    W = _potts(k, -0.5)                           # negative weight: the candidate a = b can win
+    _check(R, C, k, un, W, expect_potts=False)
+    W = _potts(k, 0.5); W[5, 5] = 0.125           # non-zero diagonal
+    _check(R, C, k, un, W, expect_potts=False)
+
+
+def test_single_row_and_single_column():
+    for R, C in ((1, 300), (300, 1), (2, 129), (1, 1)):
+        k = 32
+        _check(R, C, k, _unaries(R, C, k, R + C, quant=2), _potts(k, 0.5), iters=3)

@@ -58,6 +58,8 @@ def one(rng, idx):
         assert np.array_equal(lab, o.labels()), tag + " labels, iteration %d" % (it + 1)
     lam = np.concatenate([g.State(10).reshape(-1, C, k) for g in gs if g.StripInfo()[1] > 0], axis=0)
     assert np.array_equal(lam, o.lambda_row), tag + " multipliers"
+    lamc = np.concatenate([g.State(11).reshape(R, -1, k) for g in gs if g.StripInfo()[3] > 0], axis=1)
+    assert np.array_equal(lamc, o.lambda_col) and not np.signbit(lamc[lamc == 0]).any(), tag + " column multipliers"
     p = sum(g.Objective()[0] for g in gs)
     d = sum(g.Objective()[1] for g in gs)
     lin = sum(g.ComputeLinearObj() for g in gs)
