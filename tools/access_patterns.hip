@@ -29,6 +29,34 @@ __global__ __launch_bounds__(256) void stream_kernel(const float4 *__restrict__ 
   }
 }
 
+// streaming with a mix of NR reads per write from separate buffers (NR = 0: write only); NT:
+// non-temporal loads and stores (the data is not touched again before it leaves the caches)
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <int NR, bool WR, bool NT>
+__global__ __launch_bounds__(256) void mix_kernel(const f4v *__restrict__ a, const f4v *__restrict__ b,
+                                                  const f4v *__restrict__ c, const f4v *__restrict__ d,
+                                                  f4v *__restrict__ out, float *__restrict__ sink, long long n4) {
+  float acc = 0.f;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    f4v v = {1.f, 2.f, 3.f, 4.f};
+    const f4v *src[4] = {a, b, c, d};
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+      f4v x;
+      if (NT) x = __builtin_nontemporal_load(src[r] + i);
+      else x = src[r][i];
+      v += x;
+    }
+    if (WR) {
+      if (NT) __builtin_nontemporal_store(v, out + i);
+      else out[i] = v;
+    } else {
+      acc += v.x + v.y + v.z + v.w;
+    }
+  }
+  if (!WR && acc == 123.456f) sink[0] = acc;
+}
+
 // The sweep's pattern.  A wavefront walks two chains, half a chain each way as the sweep
 // does (left half forwards, right half backwards), one node (32 lanes x 4 B) per chain and
 // step, operands fetched D steps ahead.  COL = false: chains are rows (a step advances 128 B,
@@ -133,6 +161,33 @@ int main() {
   CK(hipMemset(th, 0, N * sizeof(float)));
   CK(hipMemset(lam, 0, N * sizeof(float)));
   const double rd = 2.0 * N * 4, wr = 1.0 * N * 4;
+  {
+    // five separate 512 MiB buffers: up to four read, one written
+    float *bufs[5];
+    for (auto &p : bufs) {
+      CK(hipMalloc(&p, N * sizeof(float)));
+      CK(hipMemset(p, 0, N * sizeof(float)));
+    }
+    const double one = 1.0 * N * 4;
+    const dim3 g(256 * 16), t(256);
+#define MIX(NR, WR, NT, label)                                                                                     \
+  timeit(label, one * (NR + (WR ? 1 : 0)), [&] {                                                                   \
+    hipLaunchKernelGGL((mix_kernel<NR, WR, NT>), g, t, 0, 0, (const f4v *)bufs[0], (const f4v *)bufs[1],     \
+                       (const f4v *)bufs[2], (const f4v *)bufs[3], (f4v *)bufs[4], sink, N / 4);          \
+  })
+    MIX(1, false, false, "stream: 1 read");
+    MIX(4, false, false, "stream: 4 reads");
+    MIX(4, false, true, "stream: 4 reads, non-temporal");
+    MIX(0, true, false, "stream: 1 write");
+    MIX(0, true, true, "stream: 1 write, non-temporal");
+    MIX(1, true, false, "stream: 1 read + 1 write");
+    MIX(1, true, true, "stream: 1 read + 1 write, non-temporal");
+    MIX(2, true, false, "stream: 2 reads + 1 write");
+    MIX(4, true, false, "stream: 4 reads + 1 write");
+    MIX(4, true, true, "stream: 4 reads + 1 write, non-temporal");
+#undef MIX
+    for (auto &p : bufs) CK(hipFree(p));
+  }
   const int rows_blocks = R / 2 * 2 / 4, cols_blocks = C / 2 * 2 / 4;  // two chains per wavefront, two halves, four wavefronts per block
   timeit("stream 2 reads + 1 write, 16 B/lane", rd + wr, [&] {
     hipLaunchKernelGGL(stream_kernel, dim3(256 * 16), dim3(256), 0, 0, (const float4 *)th, (float4 *)lam, N / 4);
