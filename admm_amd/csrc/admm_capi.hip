@@ -236,7 +236,19 @@ int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
   }
   a.wave_begin[a.nseg] = w;
   if (w == 0) return ADMM_OK;
-  const int blocks = (w + kChainBlock / 64 - 1) / (kChainBlock / 64);
+  int blocks = (w + kChainBlock / 64 - 1) / (kChainBlock / 64);
+  a.mix_blocks = 0;
+  a.mix_big = 0;
+  if (a.nseg == 2 && !getenv("ADMM_SWEEP_NOMIX")) {  // (the variable: diagnostic, workgroups filled set after set)
+    // rows and columns side by side in every workgroup (see ChainArgs)
+    const int np0 = (a.wave_begin[1] - a.wave_begin[0]) / 2, np1 = (a.wave_begin[2] - a.wave_begin[1]) / 2;
+    const int m = std::min(np0, np1);
+    if (m > 0) {
+      a.mix_blocks = m;
+      a.mix_big = np1 > np0 ? 1 : 0;
+      blocks = m + (std::max(np0, np1) - m + 1) / 2;
+    }
+  }
   hipStream_t s = c->stream;
   if (potts) {
     switch (sh.KP) {
@@ -344,6 +356,18 @@ int chain_sweep_launch(admm_ctx *c, bool dual) {
     if (!fw.empty())
       fprintf(stderr, "sweep stamps: %zu waves, forward median %.0f max %.0f, backtrack median %.0f max %.0f, span %.0f (clock ticks)\n",
               fw.size(), fw[fw.size() / 2], fw.back(), bt[bt.size() / 2], bt.back(), (double)(t1 - t0));
+    // how long the wavefronts of each set of chains ran, in deciles (the counters of
+    // different dies have different origins: only differences inside a wavefront mean anything)
+    for (int si = 0; si < a.nseg; si++) {
+      std::vector<double> du;
+      for (int w = a.wave_begin[si]; w < a.wave_begin[si + 1]; w++)
+        if (h[3 * (size_t)w + 2]) du.push_back((double)(h[3 * (size_t)w + 2] - h[3 * (size_t)w]));
+      std::sort(du.begin(), du.end());
+      if (du.empty()) continue;
+      fprintf(stderr, "  set %d: %zu waves, duration deciles", si, du.size());
+      for (int q = 0; q <= 10; q++) fprintf(stderr, " %.0f", du[std::min(du.size() - 1, du.size() * q / 10)]);
+      fprintf(stderr, "\n");
+    }
     return ADMM_OK;
   }
   if (getenv("ADMM_SWEEP_SPLIT")) {  // diagnostic: one launch per set of chains

@@ -75,6 +75,12 @@ struct ChainArgs {
   const float *Wsplit; // k*k, W / rho
   const float *WtT, *WsplitT;  // their transposes, for the right halves
   unsigned long long *stamps;  // diagnostics: 3 clock reads per wavefront, or null
+  // Two sets of chains: the first mix_blocks workgroups hold one pair of
+  // wavefronts of seg[0] and one of seg[1] each, so that every compute unit runs
+  // the same blend of the two sets whatever order the workgroups are handed
+  // out in; the workgroups after them hold two pairs of seg[mix_big], the set
+  // that has pairs left over.  0: workgroups are filled set after set.
+  int mix_blocks, mix_big;
 };
 
 constexpr int kChainBlock = 256;  // two pairs of wavefronts per workgroup (a pair = the two halves of the same chains)
@@ -287,9 +293,25 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // the wavefront index is the same in all 64 lanes: keep it (and what
   // derives from it) in scalar registers
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wave = blockIdx.x * WPB + wib;
-  if (wave >= args.wave_begin[args.nseg]) return;
-  const int si = (args.nseg > 1 && wave >= args.wave_begin[1]) ? 1 : 0;
+  int wave = blockIdx.x * WPB + wib;
+  int si;
+  if (args.mix_blocks > 0) {
+    static_assert(WPB == 4, "a workgroup is two pairs of wavefronts");
+    const int blk = blockIdx.x;
+    int wl;
+    if (blk < args.mix_blocks) {
+      si = wib >> 1;
+      wl = 2 * blk + (wib & 1);
+    } else {
+      si = args.mix_big;
+      wl = 2 * args.mix_blocks + (blk - args.mix_blocks) * WPB + wib;
+    }
+    if (wl >= args.wave_begin[si + 1] - args.wave_begin[si]) return;
+    wave = args.wave_begin[si] + wl;
+  } else {
+    if (wave >= args.wave_begin[args.nseg]) return;
+    si = (args.nseg > 1 && wave >= args.wave_begin[1]) ? 1 : 0;
+  }
   const ChainSeg &sg = args.seg[si];
 
   unsigned long long st0 = 0;
