@@ -216,12 +216,11 @@ bool potts_enabled() {
   return !(e && atoi(e) == 0);
 }
 
-// 8 or 16 labels with chains to spare: the general kernel packs them as densely and walks
-// the chains of a wavefront side by side, one lane each; measured equal or slightly ahead.
-// 2 or 4 labels: the general kernel's scan is as short, and the Potts kernel's per-chain
-// walk does not unroll 16 or 32 chains deep.
+// 8 labels or more: the Potts kernel (with four or more chains per wavefront its trace-back
+// runs one lane per chain, otherwise on the scalar unit).  2 or 4 labels: the general
+// kernel's scan is as short.
 bool potts_chosen(const admm_ctx *c, SweepShape sh) {
-  return c->potts && (sh.KP >= 32 || (sh.KP >= 8 && sh.NS > 1)) && potts_enabled();
+  return c->potts && sh.KP >= 8 && potts_enabled();
 }
 
 template <bool DUAL>

@@ -853,7 +853,118 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // copy while the chunk before it is already being fetched into registers
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // this wavefront's own back-pointer stores
   const int nchunks = Tpad / kChunk;
-  if constexpr (POTTS) {
+  if constexpr (POTTS && CPW >= 4) {
+    // Four or more chains per wavefront: one lane per chain walks.  Lane tt
+    // (= step tt of the chunk) cuts every chain's field out of the two masks
+    // and leaves  keep field | i1 << 16  in LDS, row = chain; lane q then reads
+    // its chain's row four steps at a time, walks it in registers
+    //   x_{t-1} = bit x_t of keep ? x_t : i1
+    // and puts the labels where the words were, for the lanes to pick up step
+    // by step again.  Rows are padded by four dwords so that the 16-byte
+    // accesses of the walking lanes fall into different banks.
+    constexpr int RS = kChunk + 4;
+    static_assert(CPW * RS <= CPW * 16 * KP, "the staging rows fit the back-pointer buffer");
+    uint32_t *stg = &s_bp[wib][0][0];
+    uint32_t mr[4], mn[4], mf[4];  // this chunk, the next one, in flight
+    auto load_chunk = [&](uint32_t (&dst)[4], int ci) {
+      const uint32_t *src = bpwave + (long long)ci * 256 + lane;
+#pragma unroll
+      for (int i = 0; i < 4; i++) dst[i] = src[i * 64];
+    };
+    int cur = __shfl(bi, (lane < CPW ? lane : 0) * LPC);  // lane q: the last label of chain q
+    int carry[CPW];
+    double linc[CPW];
+    float wp[CPW];
+    int *xcb[CPW];  // uniform base pointers of the chains of this wavefront
+    bool cval[CPW];
+#pragma unroll
+    for (int q = 0; q < CPW; q++) {
+      carry[q] = __builtin_amdgcn_readlane(xjoin, q * LPC);   // used by the right half only
+      linc[q] = 0.0;
+      wp[q] = 0.0f;
+      const int craw = (wlocal >> 1) * CPW + q;
+      cval[q] = craw < sg.nchains;
+      const int cq = cval[q] ? craw : sg.nchains - 1;
+      xcb[q] = sg.x + (long long)cq * Tfull + (rev ? Tfull - 1 : 0);
+    }
+    load_chunk(mr, nchunks - 1);
+    if (nchunks > 1) load_chunk(mn, nchunks - 2);
+    for (int ci = nchunks - 1; ci >= 0; ci--) {
+      const int t0 = ci * kChunk;
+      const int n = min(kChunk, T - t0);
+      if (ci > 1) load_chunk(mf, ci - 2);
+#pragma unroll
+      for (int q = 0; q < CPW; q++) {
+        constexpr uint32_t FM = (1u << KP) - 1u;
+        const uint32_t kf = ((q * KP < 32 ? mr[0] : mr[1]) >> ((q * KP) & 31)) & FM;
+        const uint32_t ef = ((q * KP < 32 ? mr[2] : mr[3]) >> ((q * KP) & 31)) & FM;
+        // at the chain's first node the masks are not used (whatever they hold
+        // gives a label below KP)
+        const uint32_t i1 = (uint32_t)__builtin_ctz(ef | (1u << (KP - 1)));
+        stg[q * RS + lane] = kf | (i1 << 16);
+      }
+      wave_lds_fence();
+      if (lane < CPW) {
+        uint4 *row = reinterpret_cast<uint4 *>(stg + lane * RS);
+        auto walk4 = [&](auto g_c, const bool guarded) {
+          constexpr int g = decltype(g_c)::value;
+          const uint4 w4 = row[g];
+          const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+          uint32_t o[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int e = 3; e >= 0; e--) {
+            if (!guarded || 4 * g + e < n) {
+              o[e] = (uint32_t)cur;
+              cur = ((w[e] >> cur) & 1u) ? cur : (int)(w[e] >> 16);
+            }
+          }
+          row[g] = uint4{o[0], o[1], o[2], o[3]};
+        };
+        if (n == kChunk) {
+          static_for<0, kChunk / 4>([&](auto r_c) { walk4(std::integral_constant<int, kChunk / 4 - 1 - decltype(r_c)::value>{}, false); });
+        } else {
+          static_for<0, kChunk / 4>([&](auto r_c) {
+            constexpr int g = kChunk / 4 - 1 - decltype(r_c)::value;
+            if (4 * g < n) walk4(std::integral_constant<int, g>{}, true);
+          });
+        }
+      }
+      wave_lds_fence();
+      int xr[CPW];
+#pragma unroll
+      for (int q = 0; q < CPW; q++) xr[q] = (int)stg[q * RS + lane];
+      wave_lds_fence();
+      // labels out, and this chunk's terms of the linear objective
+#pragma unroll
+      for (int q = 0; q < CPW; q++) {
+        linc[q] += (double)wp[q];
+        const int xi = xr[q];
+        int xn = __shfl_down(xi, 1);
+        xn = (lane == n - 1) ? carry[q] : xn;
+        const int t = t0 + lane;
+        wp[q] = 0.0f;
+        if (lane < n) {
+          if (cval[q]) xcb[q][xdir * t] = xi;
+          if (t + 1 < Tedge) wp[q] = Wsp[xi * k + xn];
+        }
+        carry[q] = __builtin_amdgcn_readlane(xi, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        mr[i] = mn[i];
+        mn[i] = mf[i];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < CPW; q++) {
+      double l = linc[q] + (double)wp[q];
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) l += __shfl_xor(l, d);
+      if (cval[q] && lane == 0) sg.chain_lin[2 * ((wlocal >> 1) * CPW + q) + rev] = l;
+    }
+    if (args.stamps && lane == 0) args.stamps[3 * (size_t)wave + 2] = __builtin_readcyclecounter();
+    return;
+  } else if constexpr (POTTS) {
     // Lane tt holds the two masks of step tt of the chunk; the walk runs on the
     // scalar unit: x_{t-1} = x_t when bit x_t of the chain's field of keep is set,
     // else the lowest set bit of the chain's field of eq.  Labels are collected

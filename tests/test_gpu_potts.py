@@ -99,6 +99,40 @@ def test_potts_kernel_matches_oracle_and_general_kernel(k, G):
     _check(R, C, k, _unaries(R, C, k, 5 + k), _potts(k, 0.75), G=G)
 
 
+@pytest.mark.parametrize("k", [5, 8, 13, 16])
+@pytest.mark.parametrize("shape", [(150, 262), (1, 300), (300, 1), (700, 40)])
+def test_potts_kernel_with_several_chains_per_wavefront(k, shape):
+    # 8 or 16 label lanes: four or eight chains share a wavefront and the trace-back runs one
+    # lane per chain (quantised unaries: ties in most steps)
+    R, C = shape
+    _check(R, C, k, _unaries(R, C, k, 11 + k, quant=4), _potts(k, 0.5), G=2 if R > 1 and C > 1 else 1)
+
+
+def test_batch_of_grids_on_the_potts_kernel():
+    import admm_amd as A
+    from oracle import oracle as O
+    R, C, k, B = 70, 90, 8, 5
+    W = _potts(k, 0.5)
+    uns = [_unaries(R, C, k, 40 + b, quant=8) for b in range(B)]
+    g = A.Grid()
+    g.SetPartitioner(A.ROW)
+    g.SetPenalties(0.5, 1.0)
+    g.SetGlobalInfo(R, C, k, batch=B)
+    g.Load(np.concatenate(uns, axis=0), W)
+    g.InitOptimization()
+    assert g.SweepKernelInfo()[2]
+    for _ in range(4):
+        g.Compute(); g.Communicate(); g.Update()
+    lab = g.Labels().reshape(B, R, C)
+    g.close()
+    for b in range(B):
+        o = O.ChainOracle(R, C, k, uns[b], W)
+        o.init()
+        for _ in range(4):
+            o.compute(); o.update()
+        assert np.array_equal(lab[b], o.labels().reshape(R, C)), "grid %d" % b
+
+
 @pytest.mark.parametrize("w", [0.0, 0.25, 1e-30, 1e30, float("inf")])
 def test_potts_weights_with_ties(w):
     # quantised unaries and a weight on the same lattice (or zero, or absorbing): ties between

@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CASES = [(2048, 2048, 8, 1), (2048, 2048, 16, 1), (2048, 2048, 24, 1), (2048, 2048, 32, 1), (1024, 1024, 64, 1), (256, 256, 8, 256)]
+CASES = [(512, 512, 8, 1), (512, 512, 16, 1), (2048, 2048, 8, 1), (2048, 2048, 16, 1), (2048, 2048, 24, 1), (2048, 2048, 32, 1), (1024, 1024, 64, 1), (256, 256, 8, 256)]
 
 WORKER = r"""
 import sys, time
