@@ -75,12 +75,15 @@ struct admm_ctx {
   // read it with the sign flipped and store nothing, and the row chains write
   // their update into lam_c, which is swapped with lam_r after the sweep.
   bool lam_shared() const { return d.nranks == 1; }
-  int *xrow_r = nullptr;   // [batch][nrows][cols]   labels of my row chains
-  int *xcolT_r = nullptr;  // [batch][cols][nrows]   column-chain labels on my rows
-  int *xrow_c = nullptr;   // [rows][ncols]          row-chain labels on my columns
-  int *xcolT_c = nullptr;  // [ncols][rows]          labels of my column chains
-  int *xo_r = nullptr;     // [batch][nrows][cols]   = xcolT_r transposed: what the row sweep reads
-  int *xo_c = nullptr;     // [batch][ncols][rows]   = xrow_c transposed: what the column sweep reads
+  // Labels the sweep reads and writes are bytes (label_t); labels that arrive
+  // from other strips are int32, the exchange's wire format.
+  label_t *xrow_r = nullptr;   // [batch][nrows][cols]   labels of my row chains
+  label_t *xcolT_c = nullptr;  // [batch][ncols][rows]   labels of my column chains
+  int *xcolT_r = nullptr;      // [cols][nrows]          column-chain labels on my rows   } several strips only: with one
+  int *xrow_c = nullptr;       // [rows][ncols]          row-chain labels on my columns   } strip they are the two above
+  label_t *xo_r = nullptr;     // [batch][nrows][cols]   column-chain labels on my rows, row-major: what the row sweep reads
+  label_t *xo_c = nullptr;     // [batch][ncols][rows]   row-chain labels on my columns, column-major: what the column sweep reads
+  bool one_strip() const { return d.nranks == 1; }
   uint8_t *bp_r = nullptr, *bp_c = nullptr;
   float *d_W = nullptr, *d_Wsplit = nullptr, *d_Wt = nullptr;
   float *d_WsplitT = nullptr, *d_WtT = nullptr;  // transposes, for the half chains swept backwards
@@ -381,11 +384,12 @@ int chain_sweep_launch(admm_ctx *c, bool dual) {
   return dual ? launch_sweep<true>(c, a, sh) : launch_sweep<false>(c, a, sh);
 }
 
-int chain_consensus(admm_ctx *c, float *m, const int *xa, const int *xbT, int nr, int nc) {
+template <typename TB>
+int chain_consensus(admm_ctx *c, float *m, const label_t *xa, const TB *xbT, int nr, int nc) {
   if (nr <= 0 || nc <= 0) return ADMM_OK;
   const int tr = (nr + 31) / 32, tc = (nc + 31) / 32;
   const long long blocks = (long long)c->d.batch * tr * tc;
-  hipLaunchKernelGGL(chain_consensus_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, m, xa,
+  hipLaunchKernelGGL(chain_consensus_kernel<TB>, dim3((unsigned)blocks), dim3(256), 0, c->stream, m, xa,
                      xbT, nr, nc, c->d.k, c->inv_k, tc, tr * tc);
   HIP_TRY(c, hipGetLastError());
   return ADMM_OK;
@@ -393,13 +397,14 @@ int chain_consensus(admm_ctx *c, float *m, const int *xa, const int *xbT, int nr
 
 // Both transpositions of Update in one launch: out0 = in0 (nr0 x nc0 per
 // grid) transposed, out1 = in1 (nr1 x nc1) transposed.
-int transpose_labels2(admm_ctx *c, int *out0, const int *in0, int nr0, int nc0, int *out1, const int *in1, int nr1, int nc1) {
+template <typename TI>
+int transpose_labels2(admm_ctx *c, label_t *out0, const TI *in0, int nr0, int nc0, label_t *out1, const TI *in1, int nr1, int nc1) {
   TransposeArgs a{};
   int blocks = 0;
-  auto add = [&](int *out, const int *in, int nr, int nc) {
+  auto add = [&](label_t *out, const TI *in, int nr, int nc) {
     if (nr <= 0 || nc <= 0) return;
     TransposeJob &j = a.job[a.njobs++];
-    const int tr = (nr + 31) / 32, tc = (nc + 31) / 32;
+    const int tr = (nr + 63) / 64, tc = (nc + 63) / 64;
     j.out = out; j.in = in; j.nr = nr; j.nc = nc; j.tiles_c = tc; j.tiles_per_grid = tr * tc;
     j.block_begin = blocks;
     blocks += c->d.batch * tr * tc;
@@ -407,7 +412,7 @@ int transpose_labels2(admm_ctx *c, int *out0, const int *in0, int nr0, int nc0, 
   add(out0, in0, nr0, nc0);
   add(out1, in1, nr1, nc1);
   if (blocks == 0) return ADMM_OK;
-  hipLaunchKernelGGL(transpose_labels_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(transpose_labels_kernel<TI>, dim3((unsigned)blocks), dim3(256), 0, c->stream, a);
   HIP_TRY(c, hipGetLastError());
   return ADMM_OK;
 }
@@ -708,7 +713,7 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
     HIP_TRY_BAIL(hipMemset(c->lam_c, 0, sizeof(float) * (ncol_nodes * k + 2 * slack)));
     c->th_r += slack; c->lam_r += slack; c->lam_c += slack;
     if (d.nranks == 1) {
-      c->th_c = c->th_r; c->xrow_c = c->xrow_r; c->xcolT_r = c->xcolT_c;
+      c->th_c = c->th_r;
     } else {
       if ((rc = dev_alloc(c, &c->th_c, ncol_nodes * k + 2 * slack)) ||
           (rc = dev_alloc(c, &c->xrow_c, ncol_nodes)) || (rc = dev_alloc(c, &c->xcolT_r, nrow_nodes)) ||
@@ -942,10 +947,15 @@ int admm_init(admm_ctx *c) {
     hipLaunchKernelGGL(chain_init_theta_kernel, dim3(grid_for(nrow * k, 256)), dim3(256), 0, s, c->th_r, nrow * k, d.rho);
     HIP_TRY(c, hipMemsetAsync(c->lam_r, 0, sizeof(float) * nrow * k, s));
     HIP_TRY(c, hipMemsetAsync(c->lam_c, 0, sizeof(float) * ncol * k, s));
-    hipLaunchKernelGGL(fill_int_kernel, dim3(grid_for(nrow, 256)), dim3(256), 0, s, c->xrow_r, nrow, -1);
-    hipLaunchKernelGGL(fill_int_kernel, dim3(grid_for(ncol, 256)), dim3(256), 0, s, c->xcolT_c, ncol, -1);
-    hipLaunchKernelGGL(fill_int_kernel, dim3(grid_for(nrow, 256)), dim3(256), 0, s, c->xo_r, nrow, -1);
-    hipLaunchKernelGGL(fill_int_kernel, dim3(grid_for(ncol, 256)), dim3(256), 0, s, c->xo_c, ncol, -1);
+    // -1 in every label, whatever its width
+    if (nrow > 0) {
+      HIP_TRY(c, hipMemsetAsync(c->xrow_r, 0xFF, sizeof(label_t) * nrow, s));
+      HIP_TRY(c, hipMemsetAsync(c->xo_r, 0xFF, sizeof(label_t) * nrow, s));
+    }
+    if (ncol > 0) {
+      HIP_TRY(c, hipMemsetAsync(c->xcolT_c, 0xFF, sizeof(label_t) * ncol, s));
+      HIP_TRY(c, hipMemsetAsync(c->xo_c, 0xFF, sizeof(label_t) * ncol, s));
+    }
     if (d.nranks > 1) {
       hipLaunchKernelGGL(chain_init_theta_kernel, dim3(grid_for(ncol * k, 256)), dim3(256), 0, s, c->th_c, ncol * k, d.rho);
       hipLaunchKernelGGL(fill_int_kernel, dim3(grid_for(nrow, 256)), dim3(256), 0, s, c->xcolT_r, nrow, -1);
@@ -1362,7 +1372,9 @@ int admm_update(admm_ctx *c) {
   // (Grid.cpp:163-181 with one-hot marginals); the sweep evaluates it from
   // them, so Update only lays each set of labels out along the crossing chains.
   // [cols][nrows] -> [nrows][cols] and [rows][ncols] -> [ncols][rows]
-  return transpose_labels2(c, c->xo_r, c->xcolT_r, d.cols, c->st.nrows, c->xo_c, c->xrow_c, d.rows, c->st.ncols);
+  if (c->one_strip())
+    return transpose_labels2<label_t>(c, c->xo_r, c->xcolT_c, d.cols, c->st.nrows, c->xo_c, c->xrow_r, d.rows, c->st.ncols);
+  return transpose_labels2<int>(c, c->xo_r, c->xcolT_r, d.cols, c->st.nrows, c->xo_c, c->xrow_c, d.rows, c->st.ncols);
 }
 
 namespace {
@@ -1624,9 +1636,11 @@ int admm_finalize(admm_ctx *c) {
   return ADMM_OK;
 }
 
+extern "C++" {
 namespace {
-__global__ void chain_decode_kernel(int *__restrict__ out, const int *__restrict__ xa,
-                                    const int *__restrict__ xbT, int nr, int nc, long long total) {
+template <typename TB>
+__global__ void chain_decode_kernel(int *__restrict__ out, const label_t *__restrict__ xa,
+                                    const TB *__restrict__ xbT, int nr, int nc, long long total) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const long long g = i / ((long long)nr * nc), rem = i % ((long long)nr * nc);
@@ -1634,7 +1648,7 @@ __global__ void chain_decode_kernel(int *__restrict__ out, const int *__restrict
     out[i] = chain_decode(xa[i], xbT[g * nr * nc + cc * nr + r]);
   }
 }
-__global__ void transpose_int_kernel(int *__restrict__ out, const int *__restrict__ in, int nr, int nc,
+__global__ void transpose_int_kernel(int *__restrict__ out, const label_t *__restrict__ in, int nr, int nc,
                                      long long total) {
   // in: [g][nc][nr] -> out: [g][nr][nc]
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -1644,7 +1658,13 @@ __global__ void transpose_int_kernel(int *__restrict__ out, const int *__restric
     out[i] = in[g * nr * nc + cc * nr + r];
   }
 }
+__global__ void widen_labels_kernel(int *__restrict__ out, const label_t *__restrict__ in, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x)
+    out[i] = in[i];
+}
 }  // namespace
+}  // extern "C++"
 
 int admm_download_labels(admm_ctx *c, int32_t *labels) {
   int rc = check_ctx(c);
@@ -1656,8 +1676,12 @@ int admm_download_labels(admm_ctx *c, int32_t *labels) {
   if (total == 0) return ADMM_OK;
   int *tmp = nullptr;
   HIP_TRY(c, hipMalloc((void **)&tmp, sizeof(int) * total));
-  hipLaunchKernelGGL(chain_decode_kernel, dim3(grid_for(total, 256)), dim3(256), 0, c->stream, tmp, c->xrow_r,
-                     c->xcolT_r, c->st.nrows, c->d.cols, total);
+  if (c->one_strip())
+    hipLaunchKernelGGL(chain_decode_kernel<label_t>, dim3(grid_for(total, 256)), dim3(256), 0, c->stream, tmp, c->xrow_r,
+                       c->xcolT_c, c->st.nrows, c->d.cols, total);
+  else
+    hipLaunchKernelGGL(chain_decode_kernel<int>, dim3(grid_for(total, 256)), dim3(256), 0, c->stream, tmp, c->xrow_r,
+                       c->xcolT_r, c->st.nrows, c->d.cols, total);
   hipError_t e = hipMemcpyAsync(labels, tmp, sizeof(int) * total, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   (void)hipFree(tmp);
@@ -1680,7 +1704,8 @@ int admm_download_consensus(admm_ctx *c, float *out) {
   if (n == 0) return ADMM_OK;
   float *tmp = nullptr;
   HIP_TRY(c, hipMalloc((void **)&tmp, sizeof(float) * n));
-  rc = chain_consensus(c, tmp, c->xrow_r, c->xcolT_r, c->st.nrows, c->d.cols);
+  rc = c->one_strip() ? chain_consensus<label_t>(c, tmp, c->xrow_r, c->xcolT_c, c->st.nrows, c->d.cols)
+                      : chain_consensus<int>(c, tmp, c->xrow_r, c->xcolT_r, c->st.nrows, c->d.cols);
   hipError_t e = rc ? hipSuccess : hipMemcpyAsync(out, tmp, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   (void)hipFree(tmp);
@@ -1735,7 +1760,12 @@ int admm_download_state(admm_ctx *c, int which, float *out) {
       case 10: src = c->lam_r; break;
       case 11: src = c->lam_shared() ? c->lam_r : c->lam_c; break;
       case 12: src = c->th_r; break;
-      case 13: src = c->xrow_r; break;
+      case 13:
+        HIP_TRY(c, hipMalloc(&tmp, sizeof(int) * n));
+        hipLaunchKernelGGL(widen_labels_kernel, dim3(grid_for((long long)n, 256)), dim3(256), 0, c->stream,
+                           (int *)tmp, c->xrow_r, (long long)n);
+        src = tmp;
+        break;
       case 14:
         // stored chain-major ([col][row]); hand it out as [row][col]
         HIP_TRY(c, hipMalloc(&tmp, sizeof(int) * n));

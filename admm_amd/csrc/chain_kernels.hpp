@@ -37,6 +37,10 @@
 
 namespace admm {
 
+// A chain's label for a node: 0 .. k-1 with k <= 64, or -1 before the first solve.
+// One byte, so that the label arrays cost the sweep a quarter of what int32 would.
+typedef int8_t label_t;
+
 // One set of chains that share a stride pattern (all row chains, or all
 // column chains).  Node t of chain c is
 //   (c / cpg) * gstride + (c % cpg) * cstride + t * sstride,
@@ -51,8 +55,8 @@ struct ChainSeg {
                        // column multipliers are the row ones negated, bit for bit; on one device the
                        // column chains read the row chains' array and store nothing, and the row chains
                        // write into a second buffer that becomes current after the sweep.
-  int *x;              // [nchains][T] labels of these chains (-1 before the first solve)
-  const int *xo;       // [nchains][T] labels the crossing chains gave the same nodes
+  label_t *x;          // [nchains][T] labels of these chains (-1 before the first solve)
+  const label_t *xo;   // [nchains][T] labels the crossing chains gave the same nodes
   uint8_t *bp;         // [nchains][2][half length padded to 64][KP] back-pointer scratch
   float *chain_min;    // [nchains] (dual evaluation only)
   double *chain_lin;   // [nchains][2] pairwise energy of the new labels per half chain: sum of (W / rho)[x_t][x_t+1]
@@ -420,8 +424,8 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_off, soff, 0));
   };
   // labels of the half in sweep order: xchain[xdir * step]
-  int *xchain = sg.x + (long long)chain * Tfull + (rev ? Tfull - 1 : 0);
-  const int *xochain = DUAL ? nullptr : sg.xo + (long long)chain * Tfull + (rev ? Tfull - 1 : 0);
+  label_t *xchain = sg.x + (long long)chain * Tfull + (rev ? Tfull - 1 : 0);
+  const label_t *xochain = DUAL ? nullptr : sg.xo + (long long)chain * Tfull + (rev ? Tfull - 1 : 0);
   const int Tpad = (T + kChunk - 1) / kChunk * kChunk;
   const int TpadH = (Lhalf + kChunk - 1) / kChunk * kChunk;  // scratch per half chain, in steps
   uint32_t *bpchain = DUAL ? nullptr : reinterpret_cast<uint32_t *>(sg.bp) + ((long long)chain * 2 + rev) * (TpadH / 4) * KP;
@@ -875,7 +879,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     int carry[CPW];
     double linc[CPW];
     float wp[CPW];
-    int *xcb[CPW];  // uniform base pointers of the chains of this wavefront
+    label_t *xcb[CPW];  // uniform base pointers of the chains of this wavefront
     bool cval[CPW];
 #pragma unroll
     for (int q = 0; q < CPW; q++) {
@@ -944,7 +948,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         const int t = t0 + lane;
         wp[q] = 0.0f;
         if (lane < n) {
-          if (cval[q]) xcb[q][xdir * t] = xi;
+          if (cval[q]) xcb[q][xdir * t] = (label_t)xi;
           if (t + 1 < Tedge) wp[q] = Wsp[xi * k + xn];
         }
         carry[q] = __builtin_amdgcn_readlane(xi, 0);
@@ -978,7 +982,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     int curs[CPW], carry[CPW];
     double linc[CPW];
     float wp[CPW];
-    int *xcb[CPW];  // uniform base pointers of the chains of this wavefront
+    label_t *xcb[CPW];  // uniform base pointers of the chains of this wavefront
     bool cval[CPW];
 #pragma unroll
     for (int q = 0; q < CPW; q++) {
@@ -1064,13 +1068,13 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         xn = (lane == n - 1) ? carry[q] : xn;
         const int t = t0 + lane;
         if (n == kChunk && cval[q]) {
-          xcb[q][xdir * t] = xi;
+          xcb[q][xdir * t] = (label_t)xi;
           const float wv = Wsp[xi * k + xn];
           wp[q] = (t + 1 < Tedge) ? wv : 0.0f;
         } else {
           wp[q] = 0.0f;
           if (lane < n) {
-            if (cval[q]) xcb[q][xdir * t] = xi;
+            if (cval[q]) xcb[q][xdir * t] = (label_t)xi;
             if (t + 1 < Tedge) wp[q] = Wsp[xi * k + xn];
           }
         }
@@ -1107,7 +1111,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     int curs[CPW], carry[CPW], wtmp[2] = {0, 0};
     double linc[CPW];
     float wp[CPW];
-    int *xcb[CPW];  // uniform base pointers of the chains of this wavefront
+    label_t *xcb[CPW];  // uniform base pointers of the chains of this wavefront
     bool cval[CPW];
 #pragma unroll
     for (int q = 0; q < CPW; q++) {
@@ -1208,13 +1212,13 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         xn = (lane == n - 1) ? carry[q] : xn;
         const int t = t0 + lane;
         if (n == kChunk && cval[q]) {
-          xcb[q][xdir * t] = xi;
+          xcb[q][xdir * t] = (label_t)xi;
           const float wv = Wsp[xi * k + xn];
           wp[q] = (t + 1 < Tedge) ? wv : 0.0f;
         } else {
           wp[q] = 0.0f;
           if (lane < n) {
-            if (cval[q]) xcb[q][xdir * t] = xi;
+            if (cval[q]) xcb[q][xdir * t] = (label_t)xi;
             if (t + 1 < Tedge) wp[q] = Wsp[xi * k + xn];
           }
         }
@@ -1308,7 +1312,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       const int i = within + q * LPC;
       if (i < n) {
         const int xi = s_x[wib][cs][i];
-        if (cvalid) xchain[xdir * (t0 + i)] = xi;
+        if (cvalid) xchain[xdir * (t0 + i)] = (label_t)xi;
         const int t = t0 + i;
         float wv = 0.0f;
         if (t + 1 < Tedge) {
@@ -1339,9 +1343,10 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
 // xa is row-major (labels of the row chains), xbT is column-major (labels of
 // the column chains, chain-major as the sweep writes them).  A workgroup
 // handles a 32 x 32 tile; the transposed read goes through LDS.
+template <typename TB>
 __global__ __launch_bounds__(256) void chain_consensus_kernel(float *__restrict__ m,
-                                                              const int *__restrict__ xa,
-                                                              const int *__restrict__ xbT, int nr,
+                                                              const label_t *__restrict__ xa,
+                                                              const TB *__restrict__ xbT, int nr,
                                                               int nc, int k, float inv_k,
                                                               int tiles_c, int tiles_per_grid) {
   __shared__ int s_a[32][33];
@@ -1416,7 +1421,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // writes one (primal, linear) partial; binary64 accumulation throughout.
 __global__ __launch_bounds__(256) void chain_objective_kernel(
     double *__restrict__ partial, const float *__restrict__ theta, const float *__restrict__ Wsplit,
-    const int *__restrict__ x_own, const int *__restrict__ x_oth, int nchains, int T, int cpg,
+    const label_t *__restrict__ x_own, const label_t *__restrict__ x_oth, int nchains, int T, int cpg,
     long long gstride, long long cstride, long long sstride, int k, int mode) {
   __shared__ float s_W[64 * 64];
   __shared__ double s_red[2][4];
@@ -1458,8 +1463,8 @@ __global__ __launch_bounds__(256) void chain_objective_kernel(
 
 // One transposition: out[g][c][r] = in[g][r][c] for g < batch, r < nr, c < nc.
 struct TransposeJob {
-  int *out;
-  const int *in;
+  label_t *out;
+  const void *in;  // label_t, or int32 (labels as they arrive from other strips)
   int nr, nc, tiles_c, tiles_per_grid;
   int block_begin;  // first workgroup of this job
 };
@@ -1469,26 +1474,40 @@ struct TransposeArgs {
 };
 
 // Up to two transpositions in one launch (Update needs both label arrays laid
-// out along the crossing chains); 32 x 32 tiles through LDS.
+// out along the crossing chains); 64 x 64 tiles through LDS, a wavefront reads
+// and writes 64 consecutive labels.
+template <typename TI>
 __global__ __launch_bounds__(256) void transpose_labels_kernel(const TransposeArgs args) {
-  __shared__ int s_t[32][33];
+  __shared__ label_t s_t[64][64 + 4];
   const int ji = (args.njobs > 1 && (int)blockIdx.x >= args.job[1].block_begin) ? 1 : 0;
   const TransposeJob &jb = args.job[ji];
-  int *__restrict__ out = jb.out;
-  const int *__restrict__ in = jb.in;
+  label_t *__restrict__ out = jb.out;
+  const TI *__restrict__ in = static_cast<const TI *>(jb.in);
   const int nr = jb.nr, nc = jb.nc, tiles_c = jb.tiles_c, tiles_per_grid = jb.tiles_per_grid;
   const int blk = blockIdx.x - jb.block_begin;
   const int g = blk / tiles_per_grid;
   const int tile = blk % tiles_per_grid;
-  const int r0 = (tile / tiles_c) * 32, c0 = (tile % tiles_c) * 32;
+  const int r0 = (tile / tiles_c) * 64, c0 = (tile % tiles_c) * 64;
   const long long base = (long long)g * nr * nc;
-  for (int i = threadIdx.x; i < 1024; i += 256) {
-    const int hi = i >> 5, lo = i & 31;
-    if (r0 + hi < nr && c0 + lo < nc) s_t[hi][lo] = in[base + (long long)(r0 + hi) * nc + c0 + lo];
+  // every load of the tile in flight at once: no branch around a load (rows and
+  // columns past the edge read the edge again and are never written out)
+  label_t v[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const int i = threadIdx.x + 256 * j;
+    const int r = min(r0 + (i >> 6), nr - 1), cc = min(c0 + (i & 63), nc - 1);
+    v[j] = (label_t)in[base + (long long)r * nc + cc];
+  }
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const int i = threadIdx.x + 256 * j;
+    s_t[i >> 6][i & 63] = v[j];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 1024; i += 256) {
-    const int hi = i >> 5, lo = i & 31;
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const int i = threadIdx.x + 256 * j;
+    const int hi = i >> 6, lo = i & 63;
     if (c0 + hi < nc && r0 + lo < nr) out[base + (long long)(c0 + hi) * nr + r0 + lo] = s_t[lo][hi];
   }
 }
@@ -1512,7 +1531,7 @@ __device__ __forceinline__ int owner_of(int i, int n, int G, int *start, int *co
 // nc * r0_h.  With own_a / own_b set, the blocks this rank would send to
 // itself (rank self) go straight to where it would receive them.
 __global__ void pack_strip_labels_kernel(int *__restrict__ send_a, int *__restrict__ send_b,
-                                         const int *__restrict__ xrow, const int *__restrict__ xcolT,
+                                         const label_t *__restrict__ xrow, const label_t *__restrict__ xcolT,
                                          int nr, int nc, int rows, int cols, int G, int self,
                                          int *__restrict__ own_a, int *__restrict__ own_b) {
   const long long na = (long long)nr * cols, nb = (long long)nc * rows;
