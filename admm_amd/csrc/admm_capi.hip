@@ -75,6 +75,11 @@ struct admm_ctx {
   // read it with the sign flipped and store nothing, and the row chains write
   // their update into lam_c, which is swapped with lam_r after the sweep.
   bool lam_shared() const { return d.nranks == 1; }
+  // The multiplier arrays hold int16 counts of penalty / 2 instead of binary32
+  // values (the LAM16 kernels): decided by admm_init, dropped for good once the
+  // counts could leave int16.
+  bool lam16 = false;
+  int lam16_sweeps = 0, lam16_limit = 32000;
   // Labels the sweep reads and writes are bytes (label_t); labels that arrive
   // from other strips are int32, the exchange's wire format.
   label_t *xrow_r = nullptr;   // [batch][nrows][cols]   labels of my row chains
@@ -149,7 +154,21 @@ int dev_alloc(admm_ctx *c, T **p, size_t n) {
     return fail(c, ADMM_E_NOMEM, "hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
   c->allocs.push_back(q);
   *p = (T *)q;
+  // ADMM_POISON=<byte> (debugging knob): every allocation starts filled with that byte, so a read
+  // of memory nothing initialised shows up on every run and not only when the memory was dirty
+  static const char *poison = getenv("ADMM_POISON");
+  if (poison) {
+    (void)hipMemset(q, atoi(poison) & 0xFF, std::max<size_t>(n, 1) * sizeof(T));
+    (void)hipDeviceSynchronize();
+  }
   return ADMM_OK;
+}
+
+// Host -> device on the context's own stream, complete on return.  (The stream does
+// not synchronise with the null stream, so nothing the kernels read goes through that one.)
+hipError_t h2d_sync(admm_ctx *c, void *dst, const void *src, size_t bytes) {
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream);
+  return e == hipSuccess ? hipStreamSynchronize(c->stream) : e;
 }
 
 int grid_for(long long n, int block) {
@@ -212,6 +231,10 @@ void launch_sweep_potts_t(const ChainArgs &a, int blocks, hipStream_t s) {
   // (16 ahead changes nothing: the kernel moves its bytes at the rate a streaming kernel does)
   hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
 }
+template <int KP>
+void launch_sweep_potts16_t(const ChainArgs &a, int blocks, hipStream_t s) {
+  hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+}
 
 // ADMM_SWEEP_POTTS=0 (tuning and test knob) keeps the general kernel on a Potts table.
 bool potts_enabled() {
@@ -223,6 +246,7 @@ bool potts_enabled() {
 // runs one lane per chain, otherwise on the scalar unit).  2 or 4 labels: the general
 // kernel's scan is as short.
 bool potts_chosen(const admm_ctx *c, SweepShape sh) {
+  if (c->lam16) return true;  // the arrays are in the form only that kernel reads
   return c->potts && sh.KP >= 8 && potts_enabled();
 }
 
@@ -252,6 +276,17 @@ int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
     }
   }
   hipStream_t s = c->stream;
+  if (potts && c->lam16) {
+    switch (sh.KP) {
+      case 8: launch_sweep_potts16_t<8>(a, blocks, s); break;
+      case 16: launch_sweep_potts16_t<16>(a, blocks, s); break;
+      case 32: launch_sweep_potts16_t<32>(a, blocks, s); break;
+      case 64: launch_sweep_potts16_t<64>(a, blocks, s); break;
+      default: return fail(c, ADMM_E_ARG, "no sweep kernel for KP=%d", sh.KP);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return ADMM_OK;
+  }
   if (potts) {
     switch (sh.KP) {
       case 8: launch_sweep_potts_t<8>(a, blocks, s); break;
@@ -312,10 +347,35 @@ void fill_seg_cols(const admm_ctx *c, ChainSeg &s, bool dual) {
 
 int chain_sweep_launch(admm_ctx *c, bool dual);
 
+// int16 counts -> binary32 multipliers: out[i] = in[i] * (penalty / 2), exact
+__global__ void widen_multipliers_kernel(float *__restrict__ out, const int16_t *__restrict__ in, long long n, float hpen) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    out[i] = (float)in[i] * hpen;
+}
+
+// The row multipliers as binary32 in the buffer the next sweep would write
+// (free between two sweeps), for readers that take binary32 only.
+int lam16_widen(admm_ctx *c) {
+  const long long n = (long long)c->d.batch * c->st.nrows * c->d.cols * c->d.k;
+  if (n > 0)
+    hipLaunchKernelGGL(widen_multipliers_kernel, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->lam_c,
+                       reinterpret_cast<const int16_t *>(c->lam_r), n, c->d.penalty * 0.5f);
+  HIP_TRY(c, hipGetLastError());
+  return ADMM_OK;
+}
+
 int chain_sweep(admm_ctx *c, bool dual) {
+  if (!dual && c->lam16 && c->lam16_sweeps >= c->lam16_limit) {
+    // a count could leave int16 from here on: binary32 for the rest of the run
+    const int rc = lam16_widen(c);
+    if (rc) return rc;
+    std::swap(c->lam_r, c->lam_c);
+    c->lam16 = false;
+  }
   const int rc = chain_sweep_launch(c, dual);
   // the row chains wrote the updated multipliers into the other buffer
   if (!rc && !dual && c->lam_shared()) std::swap(c->lam_r, c->lam_c);
+  if (!rc && !dual && c->lam16) c->lam16_sweeps++;
   return rc;
 }
 
@@ -333,6 +393,12 @@ int chain_sweep_launch(admm_ctx *c, bool dual) {
   a.WtT = dual ? c->d_WsplitT : c->d_WtT;
   a.WsplitT = c->d_WsplitT;
   SweepShape sh = pick_shape(c->KP, (long long)a.seg[0].nchains + a.seg[1].nchains);
+  if (dual && c->lam16) {
+    // the dual evaluation reads binary32 multipliers
+    const int rc = lam16_widen(c);
+    if (rc) return rc;
+    a.seg[0].lam = a.seg[1].lam = c->lam_c;
+  }
   if (!dual && getenv("ADMM_SWEEP_STAMPS")) {
     // diagnostic: per-wavefront clock stamps (start, end of forward pass, end), summarised on stderr
     const size_t nw = 2 * ((size_t)a.seg[0].nchains + a.seg[1].nchains) + 16;
@@ -663,17 +729,17 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
           (rc = dev_alloc(c, &c->d_m_part, V * k)) || (rc = dev_alloc(c, &c->d_sendv, S * k)) ||
           (rc = dev_alloc(c, &c->d_recvv, S * k)))
         return bail(rc);
-      hipError_t f1 = hipMemcpy(c->d_cnt, c->h_cnt.data(), sizeof(int) * V, hipMemcpyHostToDevice);
-      hipError_t f2 = S ? hipMemcpy(c->d_send_idx, c->h_send_idx.data(), sizeof(int) * S, hipMemcpyHostToDevice) : hipSuccess;
-      hipError_t f3 = hipMemcpy(c->d_rcv_off, rcv_off.data(), sizeof(int) * (V + 1), hipMemcpyHostToDevice);
-      hipError_t f4 = S ? hipMemcpy(c->d_rcv_pos, rcv_pos.data(), sizeof(int) * S, hipMemcpyHostToDevice) : hipSuccess;
+      hipError_t f1 = h2d_sync(c, c->d_cnt, c->h_cnt.data(), sizeof(int) * V);
+      hipError_t f2 = S ? h2d_sync(c, c->d_send_idx, c->h_send_idx.data(), sizeof(int) * S) : hipSuccess;
+      hipError_t f3 = h2d_sync(c, c->d_rcv_off, rcv_off.data(), sizeof(int) * (V + 1));
+      hipError_t f4 = S ? h2d_sync(c, c->d_rcv_pos, rcv_pos.data(), sizeof(int) * S) : hipSuccess;
       if (f1 != hipSuccess || f2 != hipSuccess || f3 != hipSuccess || f4 != hipSuccess) { c->err = "copy of the exchange plan failed"; return bail(ADMM_E_HIP); }
     }
     c->n_partial = 1024;
     if ((rc = dev_alloc(c, &c->d_partial, (size_t)c->n_partial))) return bail(rc);
-    hipError_t e1 = hipMemcpy(c->d_edges, c->h_edges.data(), sizeof(int) * 2 * E, hipMemcpyHostToDevice);
-    hipError_t e2 = hipMemcpy(c->d_inc_off, c->h_inc_off.data(), sizeof(int) * (V + 1), hipMemcpyHostToDevice);
-    hipError_t e3 = hipMemcpy(c->d_inc, c->h_inc.data(), sizeof(int) * 2 * E, hipMemcpyHostToDevice);
+    hipError_t e1 = h2d_sync(c, c->d_edges, c->h_edges.data(), sizeof(int) * 2 * E);
+    hipError_t e2 = h2d_sync(c, c->d_inc_off, c->h_inc_off.data(), sizeof(int) * (V + 1));
+    hipError_t e3 = h2d_sync(c, c->d_inc, c->h_inc.data(), sizeof(int) * 2 * E);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { c->err = "copy of the edge list failed"; return bail(ADMM_E_HIP); }
   } else {
     admm_partition(d.rows, d.nranks, d.rank, &c->st.row0, &c->st.nrows);
@@ -708,9 +774,9 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
         (rc = dev_alloc(c, &c->d_chain_unary, 2 * B * ((size_t)c->st.nrows + c->st.ncols))))
       return bail(rc);
     // [slack | data | slack]: the pointers the rest of the code sees are the data's
-    HIP_TRY_BAIL(hipMemset(c->th_r, 0, sizeof(float) * (nrow_nodes * k + 2 * slack)));
-    HIP_TRY_BAIL(hipMemset(c->lam_r, 0, sizeof(float) * (nrow_nodes * k + 2 * slack)));
-    HIP_TRY_BAIL(hipMemset(c->lam_c, 0, sizeof(float) * (ncol_nodes * k + 2 * slack)));
+    HIP_TRY_BAIL(hipMemsetAsync(c->th_r, 0, sizeof(float) * (nrow_nodes * k + 2 * slack), c->stream));
+    HIP_TRY_BAIL(hipMemsetAsync(c->lam_r, 0, sizeof(float) * (nrow_nodes * k + 2 * slack), c->stream));
+    HIP_TRY_BAIL(hipMemsetAsync(c->lam_c, 0, sizeof(float) * (ncol_nodes * k + 2 * slack), c->stream));
     c->th_r += slack; c->lam_r += slack; c->lam_c += slack;
     if (d.nranks == 1) {
       c->th_c = c->th_r;
@@ -723,7 +789,7 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
           ((rc = dev_alloc(c, &c->sendbuf_mu, (nrow_nodes + ncol_nodes) * k)) ||
            (rc = dev_alloc(c, &c->recvbuf_mu, (nrow_nodes + ncol_nodes) * k))))
         return bail(rc);
-      HIP_TRY_BAIL(hipMemset(c->th_c, 0, sizeof(float) * (ncol_nodes * k + 2 * slack)));
+      HIP_TRY_BAIL(hipMemsetAsync(c->th_c, 0, sizeof(float) * (ncol_nodes * k + 2 * slack), c->stream));
       c->th_c += slack;
     }
     c->n_partial = 2048;
@@ -842,7 +908,7 @@ int admm_upload_pairwise(admm_ctx *c, const float *table, int per_edge) {
   const size_t k2 = (size_t)c->d.k * c->d.k;
   if (is_chain(c)) {
     if (per_edge) return fail(c, ADMM_E_ARG, "the chain solver takes one shared k x k table (per_edge = 0)");
-    HIP_TRY(c, hipMemcpy(c->d_W, table, sizeof(float) * k2, hipMemcpyHostToDevice));
+    HIP_TRY(c, h2d_sync(c, c->d_W, table, sizeof(float) * k2));
   } else {
     const size_t n = per_edge ? k2 * (size_t)c->E : k2;
     if (!c->d_edge_pot || c->pair_per_edge != (per_edge ? 1 : 0)) {
@@ -850,7 +916,7 @@ int admm_upload_pairwise(admm_ctx *c, const float *table, int per_edge) {
     }
     c->pair_per_edge = per_edge ? 1 : 0;
     // a per-edge table covers the whole graph: take this rank's edges
-    HIP_TRY(c, hipMemcpy(c->d_edge_pot, table + (per_edge ? k2 * (size_t)c->e0 : 0), sizeof(float) * n, hipMemcpyHostToDevice));
+    HIP_TRY(c, h2d_sync(c, c->d_edge_pot, table + (per_edge ? k2 * (size_t)c->e0 : 0), sizeof(float) * n));
   }
   c->have_pair = true;
   c->inited = false;
@@ -971,6 +1037,18 @@ int admm_init(admm_ctx *c) {
     for (int a = 0; a < d.k && potts; a++)
       for (int b = 0; b < d.k && potts; b++) potts = (a == b) ? wt[(size_t)a * d.k + b] == 0.0f : wt[(size_t)a * d.k + b] == wt[1];
     c->potts = potts;
+    // int16 multiplier counts (the LAM16 kernels): one strip, the Potts kernel,
+    // penalty / 2 a power of two well inside the binary32 range.
+    // ADMM_LAM16=0 keeps binary32; ADMM_LAM16_LIMIT=n switches to it after n sweeps (test knobs).
+    {
+      const float hpen = d.penalty * 0.5f;
+      int ex = 0;
+      const bool pow2 = hpen > 0.0f && std::frexp(hpen, &ex) == 0.5f && ex > -100 && ex < 100;
+      const char *e16 = getenv("ADMM_LAM16"), *elim = getenv("ADMM_LAM16_LIMIT");
+      c->lam16 = c->one_strip() && potts && c->KP >= 8 && potts_enabled() && pow2 && !(e16 && atoi(e16) == 0);
+      c->lam16_sweeps = 0;
+      c->lam16_limit = elim ? std::max(0, std::min(32000, atoi(elim))) : 32000;
+    }
   }
   HIP_TRY(c, hipStreamSynchronize(s));
   c->inited = true;
@@ -1757,8 +1835,16 @@ int admm_download_state(admm_ctx *c, int which, float *out) {
     }
   } else {
     switch (which) {
-      case 10: src = c->lam_r; break;
-      case 11: src = c->lam_shared() ? c->lam_r : c->lam_c; break;
+      case 10: case 11:
+        if (c->lam16) {
+          HIP_TRY(c, hipMalloc(&tmp, sizeof(float) * n));
+          hipLaunchKernelGGL(widen_multipliers_kernel, dim3(grid_for((long long)n, 256)), dim3(256), 0, c->stream,
+                             (float *)tmp, reinterpret_cast<const int16_t *>(c->lam_r), (long long)n, c->d.penalty * 0.5f);
+          src = tmp;
+        } else {
+          src = (which == 10 || c->lam_shared()) ? c->lam_r : c->lam_c;
+        }
+        break;
       case 12: src = c->th_r; break;
       case 13:
         HIP_TRY(c, hipMalloc(&tmp, sizeof(int) * n));

@@ -50,6 +50,7 @@ struct ChainSeg {
   const float *theta;  // per-copy share of the unaries
   const float *lam;    // Lagrange multipliers of these chains, as read ...
   float *lam_out;      // ... and where the updated ones go (may be lam itself); null: not stored
+                       // (kernels built with LAM16 read and write int16 counts through both, see there)
   unsigned lam_sign;   // 0, or 0x80000000: lam holds the multipliers negated.  The two copies of a node
                        // get opposite increments (mu_row - m = -(mu_col - m)), so starting from zero the
                        // column multipliers are the row ones negated, bit for bit; on one device the
@@ -251,15 +252,22 @@ constexpr unsigned long long kFieldLsb = W >= 64 ? 1ull : (~0ull / ((1ull << (W 
 // MINW : wavefronts per SIMD the register allocation must leave room for
 // DUAL : evaluate the chain minimum under theta + lambda only (no dual
 //        update, no back-pointers, no labels)
+// LAM16: the multiplier arrays hold int16 counts n with lambda = n * penalty / 2.
+//        Every update adds -penalty/2, 0 or +penalty/2, so when penalty is a power
+//        of two and the counts stay below 2^15 the binary32 sums are exact multiples
+//        and the count is the same number in half of the bytes.  The
+//        host picks these kernels only under those conditions and turns the counts
+//        into binary32 before they could overflow.
 //
 // Back-pointers: byte (t, b) = lowest source label attaining the minimum for
 // target b at step t.  They are packed four steps to a dword and written
 // straight from registers, dword (t/4)*KP + b of the half chain's scratch;
 // the backtrack streams them back one 64-step chunk at a time (t counts the
 // steps of the half chain in sweep order).
-template <int KP, int NS, int GPB, int MINW, bool DUAL, bool POTTS = false>
+template <int KP, int NS, int GPB, int MINW, bool DUAL, bool POTTS = false, bool LAM16 = false>
 __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const ChainArgs args) {
   static_assert(!POTTS || (NS == 1 && !DUAL), "the Potts step keeps a label's message in its one lane");
+  static_assert(!LAM16 || (NS == 1 && !DUAL), "int16 multipliers: one step per load group, never the dual evaluation");
   constexpr int LPC = KP * NS;   // lanes per chain
   constexpr int CPW = 64 / LPC;  // chains per wavefront
   constexpr int A = KP / NS;     // source labels scanned per lane
@@ -411,17 +419,36 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   const unsigned soff0 = rev ? 4u * nstride * (reach - (unsigned)(NS - 1)) : 0u;
   const long long base_el = first0 * k - (rev ? (long long)reach * nstride : 0);
   const __amdgpu_buffer_rsrc_t th_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sg.theta + base_el), 0, 0xFFFFFFFF, kRsrcWord3);
-  const __amdgpu_buffer_rsrc_t lam_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sg.lam + base_el), 0, 0xFFFFFFFF, kRsrcWord3);
-  const __amdgpu_buffer_rsrc_t lamo_rs = __builtin_amdgcn_make_buffer_rsrc((sg.lam_out ? sg.lam_out : const_cast<float *>(sg.lam)) + base_el, 0, 0xFFFFFFFF, kRsrcWord3);
+  // (int16 counts: the same element offsets, two bytes each)
+  float *const lam_out_or_in = sg.lam_out ? sg.lam_out : const_cast<float *>(sg.lam);
+  const __amdgpu_buffer_rsrc_t lam_rs = __builtin_amdgcn_make_buffer_rsrc(
+      LAM16 ? (void *)(reinterpret_cast<int16_t *>(const_cast<float *>(sg.lam)) + base_el) : (void *)const_cast<float *>(sg.lam + base_el),
+      0, 0xFFFFFFFF, kRsrcWord3);
+  const __amdgpu_buffer_rsrc_t lamo_rs = __builtin_amdgcn_make_buffer_rsrc(
+      LAM16 ? (void *)(reinterpret_cast<int16_t *>(lam_out_or_in) + base_el) : (void *)(lam_out_or_in + base_el),
+      0, 0xFFFFFFFF, kRsrcWord3);
   const unsigned lam_sign = sg.lam_sign;
+  // int16 counts: count * (+-penalty / 2) is the multiplier with the set's sign on it
+  const float shpen = lam_sign ? -hpen : hpen;
+  const unsigned sstep_l = rev ? 0u - 2u * nstride : 2u * nstride;
+  const unsigned soff0_l = rev ? 2u * nstride * (reach - (unsigned)(NS - 1)) : 0u;
   // the lane's own step of group 0, in bytes
   const unsigned lane_off = 4u * ((unsigned)((first - first0) * k) + (unsigned)(rev ? NS - 1 - s : s) * nstride + (unsigned)b);
   // Stores of lanes that own no label (padding past k, the duplicate of a
   // clamped chain) get an offset beyond the descriptor's range, which the
   // hardware drops: no branch around the store.
-  const unsigned lane_off_st = (lvalid && sg.lam_out) ? lane_off : 0xFFFFFFFFu;
+  const unsigned lane_off_st = (lvalid && sg.lam_out) ? (LAM16 ? lane_off >> 1 : lane_off) : 0xFFFFFFFFu;
   auto buf_load = [&](const __amdgpu_buffer_rsrc_t &r, unsigned soff) -> float {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_off, soff, 0));
+  };
+  // a multiplier: binary32, or (LAM16) the int16 count, sign-extended, as the bits of the float
+  auto lam_load = [&](unsigned step) -> float {
+    if constexpr (LAM16) {
+      const short n = __builtin_bit_cast(short, __builtin_amdgcn_raw_buffer_load_b16(lam_rs, lane_off >> 1, soff0_l + step * sstep_l, 0));
+      return __int_as_float((int)n);
+    } else {
+      return buf_load(lam_rs, soff0 + step * sstep);
+    }
   };
   // labels of the half in sweep order: xchain[xdir * step]
   label_t *xchain = sg.x + (long long)chain * Tfull + (rev ? Tfull - 1 : 0);
@@ -449,7 +476,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   for (int j = 0; j < GPB; j++) {
     const unsigned soff = soff0 + (unsigned)(j * NS) * sstep;
     pth[j] = buf_load(th_rs, soff);
-    plam[j] = buf_load(lam_rs, soff);
+    plam[j] = lam_load((unsigned)(j * NS));
   }
   int xnext = -1, xonext = -1;  // labels of the next 64-step chunk, in flight
   if (!DUAL) {
@@ -573,7 +600,9 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       constexpr int j = decltype(j_c)::value;
       const int tg = tb + j * NS;
       const bool glive = FULL || tg < T;
-      const float th_in = pth[j], lam_in = __uint_as_float(__float_as_uint(plam[j]) ^ lam_sign);
+      const float th_in = pth[j];
+      const int n_in = __float_as_int(plam[j]);  // LAM16: the count
+      const float lam_in = LAM16 ? (float)n_in * shpen : __uint_as_float(__float_as_uint(plam[j]) ^ lam_sign);
       const unsigned goff = soff0 + (unsigned)tg * sstep;  // uniform
       float th_own = INF;
       if (DUAL) {
@@ -591,7 +620,13 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         asm("" : "+v"(th_sel));
         unary_acc += (double)th_sel;
         const float la = lam_in + p;                          // Tree.cpp:70
-        if (FULL || tg + s < T) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(la), lamo_rs, lane_off_st, goff, 0);
+        if constexpr (LAM16) {
+          const int n_out = n_in + (int)(xown == b) - (int)(xoth == b);
+          if (FULL || tg + s < T)
+            __builtin_amdgcn_raw_buffer_store_b16((short)n_out, lamo_rs, lane_off_st, soff0_l + (unsigned)tg * sstep_l, 0);
+        } else {
+          if (FULL || tg + s < T) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(la), lamo_rs, lane_off_st, goff, 0);
+        }
         th_own = rho * (th_in + la) + p;                      // Tree.cpp:85-86
       }
       static_for<0, NS>([&](auto u_c) {
@@ -619,7 +654,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
           }
           const unsigned poff = goff + (unsigned)BLK * sstep;
           pth[j] = buf_load(th_rs, poff);
-          plam[j] = buf_load(lam_rs, poff);
+          plam[j] = lam_load((unsigned)(tg + BLK));
         }
         // memory instructions stay where they are written; with one wavefront
         // per SIMD (a split chain) letting ALU work cross pays, with two it does not

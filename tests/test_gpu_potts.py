@@ -16,7 +16,7 @@ def _potts(k, w):
     return W
 
 
-def _run_gpu(R, C, k, un, W, G, iters, potts_env):
+def _run_gpu(R, C, k, un, W, G, iters, potts_env, penalty=0.5):
     import admm_amd as A
     old = os.environ.get("ADMM_SWEEP_POTTS")
     if potts_env is None:
@@ -28,7 +28,7 @@ def _run_gpu(R, C, k, un, W, G, iters, potts_env):
         for r in range(G):
             g = A.Grid(rank=r, nprocs=G)
             g.SetPartitioner(A.ROW)
-            g.SetPenalties(0.5, 1.0)
+            g.SetPenalties(penalty, 1.0)
             g.SetGlobalInfo(R, C, k)
             g.Load(un, W)
             g.InitOptimization()
@@ -58,17 +58,17 @@ def _run_gpu(R, C, k, un, W, G, iters, potts_env):
             os.environ["ADMM_SWEEP_POTTS"] = old
 
 
-def _check(R, C, k, un, W, G=1, iters=4, expect_potts=True):
+def _check(R, C, k, un, W, G=1, iters=4, expect_potts=True, penalty=0.5):
     from oracle import oracle as O
-    o = O.ChainOracle(R, C, k, un, W)
+    o = O.ChainOracle(R, C, k, un, W, penalty=penalty)
     o.init()
     ref_labels = []
     for _ in range(iters):
         o.compute(); o.update()
         ref_labels.append(o.labels().copy())
-    a = _run_gpu(R, C, k, un, W, G, iters, None)
+    a = _run_gpu(R, C, k, un, W, G, iters, None, penalty)
     assert all(i[2] == expect_potts for i in a["info"]), a["info"]
-    b = _run_gpu(R, C, k, un, W, G, iters, "0")
+    b = _run_gpu(R, C, k, un, W, G, iters, "0", penalty)
     assert not any(i[2] for i in b["info"]), b["info"]
     for name, r in (("potts kernel" if expect_potts else "default kernel", a), ("general kernel", b)):
         for it in range(iters):
@@ -131,6 +131,29 @@ def test_batch_of_grids_on_the_potts_kernel():
         for _ in range(4):
             o.compute(); o.update()
         assert np.array_equal(lab[b], o.labels().reshape(R, C)), "grid %d" % b
+
+
+@pytest.mark.parametrize("penalty", [0.5, 0.3, 4.0, 2.0 ** -20, 1.5])
+@pytest.mark.parametrize("k", [8, 32])
+def test_multipliers_as_counts_and_as_binary32(penalty, k):
+    # One strip + Potts kernel + penalty / 2 a power of two: the multiplier arrays hold int16
+    # counts.  Any other penalty keeps binary32.  Both against the oracle, bit for bit.
+    R, C = 90, 200
+    _check(R, C, k, _unaries(R, C, k, 21 + k, quant=4), _potts(k, 0.5), iters=6, penalty=penalty)
+
+
+@pytest.mark.parametrize("limit", ["0", "1", "3"])
+def test_counts_turn_into_binary32_in_mid_run(limit, monkeypatch):
+    # ADMM_LAM16_LIMIT: the switch that would come after 32000 sweeps, made to come after 0, 1, 3
+    monkeypatch.setenv("ADMM_LAM16_LIMIT", limit)
+    R, C, k = 70, 150, 32
+    _check(R, C, k, _unaries(R, C, k, 77, quant=4), _potts(k, 0.5), iters=6)
+
+
+def test_binary32_multipliers_on_request(monkeypatch):
+    monkeypatch.setenv("ADMM_LAM16", "0")
+    R, C, k = 70, 150, 16
+    _check(R, C, k, _unaries(R, C, k, 78, quant=4), _potts(k, 0.5), iters=5)
 
 
 @pytest.mark.parametrize("w", [0.0, 0.25, 1e-30, 1e30, float("inf")])

@@ -19,7 +19,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SWEEP = "chain_sweep_kernel<32, 1, 8, 4, false, true>"
+SWEEP = "chain_sweep_kernel<32, 1, 8, 4, false, true, true>"
 WORKLOAD = "2048x2048_k32_potts"
 
 

@@ -3,7 +3,7 @@
 tables, strip counts and exchange modes, every iteration's chain labels and the final
 multipliers bit-compared with the CPU oracle.
 
-    python tools/stress_parity.py [cases] [seed]
+    python tools/stress_parity.py [cases] [seed] [first case to run]
 """
 import os
 import sys
@@ -15,7 +15,7 @@ import admm_amd as A  # noqa: E402
 from oracle import oracle as O  # noqa: E402  (checker)
 
 
-def one(rng, idx):
+def one(rng, idx, skip=False):
     k = int(rng.choice([2, 3, 4, 5, 7, 8, 11, 16, 17, 24, 32, 33, 48, 64]))
     shape = rng.integers(0, 4)
     if shape == 0:
@@ -28,7 +28,10 @@ def one(rng, idx):
     exchange = int(rng.integers(0, 2)) if G > 1 else 0
     pw = str(rng.choice(["potts", "trunc_linear", "dense"]))
     quant = bool(rng.integers(0, 3) == 0)
-    un, W = O.synth_problem(R, C, k, int(rng.integers(1, 10**6)), pw)
+    seed = int(rng.integers(1, 10**6))
+    if skip:  # only the draws, so that a later case can be run on its own
+        return None
+    un, W = O.synth_problem(R, C, k, seed, pw)
     if quant:  # quantised costs: many exact ties
         un = (np.floor(un * 4) / 4).astype(np.float32)
         W = (np.floor(W * 4) / 4).astype(np.float32)
@@ -74,8 +77,9 @@ def one(rng, idx):
 if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     for i in range(cases):
-        t = one(rng, i)
-        if i % 20 == 0:
+        t = one(rng, i, skip=i < first)
+        if i % 20 == 0 and t:
             print("ok", t, flush=True)
     print("%d random cases bit-exact" % cases)
