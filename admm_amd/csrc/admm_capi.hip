@@ -80,6 +80,8 @@ struct admm_ctx {
   // counts could leave int16.
   bool lam16 = false;
   int lam16_sweeps = 0, lam16_limit = 32000;
+  size_t lam_slack = 0;                          // floats of slack on either side of a multiplier array
+  float *lamf_r = nullptr, *lamf_c = nullptr;    // several strips: binary32 copies, allocated when first needed
   // Labels the sweep reads and writes are bytes (label_t); labels that arrive
   // from other strips are int32, the exchange's wire format.
   label_t *xrow_r = nullptr;   // [batch][nrows][cols]   labels of my row chains
@@ -353,23 +355,53 @@ __global__ void widen_multipliers_kernel(float *__restrict__ out, const int16_t 
     out[i] = (float)in[i] * hpen;
 }
 
-// The row multipliers as binary32 in the buffer the next sweep would write
-// (free between two sweeps), for readers that take binary32 only.
-int lam16_widen(admm_ctx *c) {
-  const long long n = (long long)c->d.batch * c->st.nrows * c->d.cols * c->d.k;
-  if (n > 0)
-    hipLaunchKernelGGL(widen_multipliers_kernel, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->lam_c,
-                       reinterpret_cast<const int16_t *>(c->lam_r), n, c->d.penalty * 0.5f);
+// The multipliers as binary32, for readers that take binary32 only.  One strip:
+// the one array, widened into the buffer the next sweep would write (free
+// between two sweeps).  Several strips: both arrays, into two buffers of their
+// own that are allocated when first needed.
+int lam16_widen(admm_ctx *c, const float **fr, const float **fc) {
+  const long long nr = (long long)c->d.batch * c->st.nrows * c->d.cols * c->d.k;
+  const long long nc = (long long)c->d.batch * c->d.rows * c->st.ncols * c->d.k;
+  const float hpen = c->d.penalty * 0.5f;
+  float *dr = c->lam_c, *dc = nullptr;
+  if (!c->one_strip()) {
+    if (!c->lamf_r) {
+      int rc;
+      if ((rc = dev_alloc(c, &c->lamf_r, (size_t)nr + 2 * c->lam_slack)) || (rc = dev_alloc(c, &c->lamf_c, (size_t)nc + 2 * c->lam_slack)))
+        return rc;
+      HIP_TRY(c, hipMemsetAsync(c->lamf_r, 0, sizeof(float) * ((size_t)nr + 2 * c->lam_slack), c->stream));
+      HIP_TRY(c, hipMemsetAsync(c->lamf_c, 0, sizeof(float) * ((size_t)nc + 2 * c->lam_slack), c->stream));
+      c->lamf_r += c->lam_slack;
+      c->lamf_c += c->lam_slack;
+    }
+    dr = c->lamf_r;
+    dc = c->lamf_c;
+  }
+  if (nr > 0)
+    hipLaunchKernelGGL(widen_multipliers_kernel, dim3(grid_for(nr, 256)), dim3(256), 0, c->stream, dr,
+                       reinterpret_cast<const int16_t *>(c->lam_r), nr, hpen);
+  if (dc && nc > 0)
+    hipLaunchKernelGGL(widen_multipliers_kernel, dim3(grid_for(nc, 256)), dim3(256), 0, c->stream, dc,
+                       reinterpret_cast<const int16_t *>(c->lam_c), nc, hpen);
   HIP_TRY(c, hipGetLastError());
+  *fr = dr;
+  *fc = dc ? dc : dr;
   return ADMM_OK;
 }
 
 int chain_sweep(admm_ctx *c, bool dual) {
   if (!dual && c->lam16 && c->lam16_sweeps >= c->lam16_limit) {
     // a count could leave int16 from here on: binary32 for the rest of the run
-    const int rc = lam16_widen(c);
+    const float *fr = nullptr, *fc = nullptr;
+    const int rc = lam16_widen(c, &fr, &fc);
     if (rc) return rc;
-    std::swap(c->lam_r, c->lam_c);
+    if (c->one_strip()) {
+      std::swap(c->lam_r, c->lam_c);
+    } else {
+      c->lam_r = c->lamf_r;
+      c->lam_c = c->lamf_c;
+      c->lamf_r = c->lamf_c = nullptr;  // now the arrays themselves; a later copy gets buffers of its own
+    }
     c->lam16 = false;
   }
   const int rc = chain_sweep_launch(c, dual);
@@ -395,9 +427,11 @@ int chain_sweep_launch(admm_ctx *c, bool dual) {
   SweepShape sh = pick_shape(c->KP, (long long)a.seg[0].nchains + a.seg[1].nchains);
   if (dual && c->lam16) {
     // the dual evaluation reads binary32 multipliers
-    const int rc = lam16_widen(c);
+    const float *fr = nullptr, *fc = nullptr;
+    const int rc = lam16_widen(c, &fr, &fc);
     if (rc) return rc;
-    a.seg[0].lam = a.seg[1].lam = c->lam_c;
+    a.seg[0].lam = fr;
+    a.seg[1].lam = fc;
   }
   if (!dual && getenv("ADMM_SWEEP_STAMPS")) {
     // diagnostic: per-wavefront clock stamps (start, end of forward pass, end), summarised on stderr
@@ -758,6 +792,7 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
     const size_t slack_r = 64 * (size_t)std::max(d.cols, 1) * k;
     const size_t slack_c = 64 * (size_t)std::max(d.nranks == 1 ? d.cols : c->st.ncols, 1) * k;
     const size_t slack = std::max(slack_r, slack_c);
+    c->lam_slack = slack;
     if ((rc = dev_alloc(c, &c->th_r, nrow_nodes * k + 2 * slack)) || (rc = dev_alloc(c, &c->lam_r, nrow_nodes * k + 2 * slack)) ||
         (rc = dev_alloc(c, &c->lam_c, ncol_nodes * k + 2 * slack)) ||
         (rc = dev_alloc(c, &c->xrow_r, nrow_nodes)) || (rc = dev_alloc(c, &c->xcolT_c, ncol_nodes)) ||
@@ -1037,7 +1072,7 @@ int admm_init(admm_ctx *c) {
     for (int a = 0; a < d.k && potts; a++)
       for (int b = 0; b < d.k && potts; b++) potts = (a == b) ? wt[(size_t)a * d.k + b] == 0.0f : wt[(size_t)a * d.k + b] == wt[1];
     c->potts = potts;
-    // int16 multiplier counts (the LAM16 kernels): one strip, the Potts kernel,
+    // int16 multiplier counts (the LAM16 kernels): the Potts kernel,
     // penalty / 2 a power of two well inside the binary32 range.
     // ADMM_LAM16=0 keeps binary32; ADMM_LAM16_LIMIT=n switches to it after n sweeps (test knobs).
     {
@@ -1045,7 +1080,7 @@ int admm_init(admm_ctx *c) {
       int ex = 0;
       const bool pow2 = hpen > 0.0f && std::frexp(hpen, &ex) == 0.5f && ex > -100 && ex < 100;
       const char *e16 = getenv("ADMM_LAM16"), *elim = getenv("ADMM_LAM16_LIMIT");
-      c->lam16 = c->one_strip() && potts && c->KP >= 8 && potts_enabled() && pow2 && !(e16 && atoi(e16) == 0);
+      c->lam16 = potts && c->KP >= 8 && potts_enabled() && pow2 && !(e16 && atoi(e16) == 0);
       c->lam16_sweeps = 0;
       c->lam16_limit = elim ? std::max(0, std::min(32000, atoi(elim))) : 32000;
     }
@@ -1839,7 +1874,8 @@ int admm_download_state(admm_ctx *c, int which, float *out) {
         if (c->lam16) {
           HIP_TRY(c, hipMalloc(&tmp, sizeof(float) * n));
           hipLaunchKernelGGL(widen_multipliers_kernel, dim3(grid_for((long long)n, 256)), dim3(256), 0, c->stream,
-                             (float *)tmp, reinterpret_cast<const int16_t *>(c->lam_r), (long long)n, c->d.penalty * 0.5f);
+                             (float *)tmp, reinterpret_cast<const int16_t *>((which == 10 || c->lam_shared()) ? c->lam_r : c->lam_c),
+                             (long long)n, c->d.penalty * 0.5f);
           src = tmp;
         } else {
           src = (which == 10 || c->lam_shared()) ? c->lam_r : c->lam_c;

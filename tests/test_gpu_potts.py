@@ -140,14 +140,16 @@ def test_multipliers_as_counts_and_as_binary32(penalty, k):
     # counts.  Any other penalty keeps binary32.  Both against the oracle, bit for bit.
     R, C = 90, 200
     _check(R, C, k, _unaries(R, C, k, 21 + k, quant=4), _potts(k, 0.5), iters=6, penalty=penalty)
+    _check(R, C, k, _unaries(R, C, k, 22 + k, quant=4), _potts(k, 0.5), G=2, iters=4, penalty=penalty)
 
 
 @pytest.mark.parametrize("limit", ["0", "1", "3"])
-def test_counts_turn_into_binary32_in_mid_run(limit, monkeypatch):
+@pytest.mark.parametrize("G", [1, 3])
+def test_counts_turn_into_binary32_in_mid_run(limit, G, monkeypatch):
     # ADMM_LAM16_LIMIT: the switch that would come after 32000 sweeps, made to come after 0, 1, 3
     monkeypatch.setenv("ADMM_LAM16_LIMIT", limit)
     R, C, k = 70, 150, 32
-    _check(R, C, k, _unaries(R, C, k, 77, quant=4), _potts(k, 0.5), iters=6)
+    _check(R, C, k, _unaries(R, C, k, 77, quant=4), _potts(k, 0.5), G=G, iters=6)
 
 
 def test_binary32_multipliers_on_request(monkeypatch):
