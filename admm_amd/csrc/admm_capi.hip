@@ -235,6 +235,7 @@ void launch_sweep_potts_t(const ChainArgs &a, int blocks, hipStream_t s) {
 }
 template <int KP>
 void launch_sweep_potts16_t(const ChainArgs &a, int blocks, hipStream_t s) {
+  // (operands 16 steps ahead instead of 8: 1 to 2 % slower; 32: spills)
   hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
 }
 
@@ -437,18 +438,18 @@ int chain_sweep_launch(admm_ctx *c, bool dual) {
     // diagnostic: per-wavefront clock stamps (start, end of forward pass, end), summarised on stderr
     const size_t nw = 2 * ((size_t)a.seg[0].nchains + a.seg[1].nchains) + 16;
     unsigned long long *d_st = nullptr;
-    HIP_TRY(c, hipMalloc((void **)&d_st, nw * 3 * sizeof(unsigned long long)));
-    HIP_TRY(c, hipMemset(d_st, 0, nw * 3 * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMalloc((void **)&d_st, nw * 4 * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMemset(d_st, 0, nw * 4 * sizeof(unsigned long long)));
     a.stamps = d_st;
     int rc = launch_sweep<false>(c, a, sh);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    std::vector<unsigned long long> h(nw * 3);
+    std::vector<unsigned long long> h(nw * 4);
     HIP_TRY(c, hipMemcpy(h.data(), d_st, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     (void)hipFree(d_st);
     std::vector<double> fw, bt;
     unsigned long long t0 = ~0ull, t1 = 0;
-    for (size_t w = 0; w < nw; w++) {
+    for (size_t w = 0; w < (size_t)a.wave_begin[a.nseg]; w++) {
       if (!h[3 * w + 2]) continue;
       fw.push_back((double)(h[3 * w + 1] - h[3 * w]));
       bt.push_back((double)(h[3 * w + 2] - h[3 * w + 1]));
@@ -469,6 +470,47 @@ int chain_sweep_launch(admm_ctx *c, bool dual) {
       fprintf(stderr, "  set %d: %zu waves, duration deciles", si, du.size());
       for (int q = 0; q <= 10; q++) fprintf(stderr, " %.0f", du[std::min(du.size() - 1, du.size() * q / 10)]);
       fprintf(stderr, "\n");
+    }
+    // mean duration by die, by shader engine, by compute unit of a shader engine, by half (left / right)
+    {
+      const size_t W = (size_t)a.wave_begin[a.nseg];
+      double sx[16] = {0}, ss[8] = {0}, sc[16] = {0}, sr[2] = {0};
+      int nx[16] = {0}, ns[8] = {0}, nc[16] = {0}, nr[2] = {0};
+      for (size_t w = 0; w < W; w++) {
+        if (!h[3 * w + 2]) continue;
+        const double du = (double)(h[3 * w + 2] - h[3 * w]);
+        const unsigned long long id = h[3 * W + w];
+        const int xcc = (int)(id >> 32) & 15, hw = (int)(id & 0xFFFFFFFFu);
+        const int cu = (hw >> 8) & 15, se = (hw >> 13) & 7;
+        sx[xcc] += du; nx[xcc]++; ss[se] += du; ns[se]++; sc[cu] += du; nc[cu]++;
+        sr[w & 1] += du; nr[w & 1]++;
+      }
+      fprintf(stderr, "  by die:");
+      for (int i = 0; i < 16; i++) if (nx[i]) fprintf(stderr, " %d:%.0f(%d)", i, sx[i] / nx[i], nx[i]);
+      fprintf(stderr, "\n  by shader engine:");
+      for (int i = 0; i < 8; i++) if (ns[i]) fprintf(stderr, " %d:%.0f(%d)", i, ss[i] / ns[i], ns[i]);
+      fprintf(stderr, "\n  by compute unit id:");
+      for (int i = 0; i < 16; i++) if (nc[i]) fprintf(stderr, " %d:%.0f(%d)", i, sc[i] / nc[i], nc[i]);
+      fprintf(stderr, "\n  left halves %.0f, right halves %.0f\n", nr[0] ? sr[0] / nr[0] : 0.0, nr[1] ? sr[1] / nr[1] : 0.0);
+      // by position of the chains in their set (16 bins), with the mean start offset inside the die
+      unsigned long long first_start[16];
+      for (int i = 0; i < 16; i++) first_start[i] = ~0ull;
+      for (size_t w = 0; w < W; w++)
+        if (h[3 * w + 2]) { const int x = (int)(h[3 * W + w] >> 32) & 15; first_start[x] = std::min(first_start[x], h[3 * w]); }
+      for (int si = 0; si < a.nseg; si++) {
+        const int w0 = a.wave_begin[si], w1 = a.wave_begin[si + 1];
+        fprintf(stderr, "  set %d by chain position, duration(start offset):", si);
+        for (int bin = 0; bin < 16; bin++) {
+          double sd = 0, so = 0; int n = 0;
+          for (int w = w0 + (int)((long long)(w1 - w0) * bin / 16); w < w0 + (int)((long long)(w1 - w0) * (bin + 1) / 16); w++) {
+            if (!h[3 * (size_t)w + 2]) continue;
+            const int x = (int)(h[3 * W + w] >> 32) & 15;
+            sd += (double)(h[3 * (size_t)w + 2] - h[3 * (size_t)w]); so += (double)(h[3 * (size_t)w] - first_start[x]); n++;
+          }
+          if (n) fprintf(stderr, " %.0f(%.0f)", sd / n, so / n);
+        }
+        fprintf(stderr, "\n");
+      }
     }
     return ADMM_OK;
   }
