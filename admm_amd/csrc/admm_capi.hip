@@ -1595,6 +1595,37 @@ __global__ __launch_bounds__(1024) void linear_reduce2_kernel(const Reduce2Args 
     a.dst[j][0] = t;
   }
 }
+// Many terms (a batch of grids has one per half chain of every grid): kStage1
+// workgroups per sum leave partial sums of contiguous slices in `mid`, and
+// linear_reduce2_kernel then sums those.  One workgroup alone would walk
+// megabytes at the latency of a single wavefront's loads.
+constexpr int kStage1 = 256;
+__global__ __launch_bounds__(256) void linear_stage1_kernel(const Reduce2Args a, double *__restrict__ mid) {
+  __shared__ double s_red[4];
+  const int j = blockIdx.y, b = blockIdx.x;
+  const double *__restrict__ part = a.part[j];
+  const int n = a.n[j];
+  const int per = (n + kStage1 - 1) / kStage1;
+  const int lo = b * per, hi = min(n, lo + per);
+  double l = 0.0;
+  for (int i = lo + (int)threadIdx.x; i < hi; i += 256) l += part[i];
+  l = wave_sum(l);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = l;
+  __syncthreads();
+  if (threadIdx.x == 0) mid[j * kStage1 + b] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// Up to two sums, queued on the context's stream.
+int launch_reduce2(admm_ctx *c, Reduce2Args a, int jobs) {
+  if (a.n[0] > 64 * 1024) {
+    static_assert(2 * kStage1 <= 2048 * 2, "the partial-sum buffer holds both jobs");
+    hipLaunchKernelGGL(linear_stage1_kernel, dim3(kStage1, jobs), dim3(256), 0, c->stream, a, c->d_partial);
+    for (int j = 0; j < jobs; j++) { a.part[j] = c->d_partial + j * kStage1; a.n[j] = kStage1; }
+  }
+  hipLaunchKernelGGL(linear_reduce2_kernel, dim3(jobs), dim3(1024), 0, c->stream, a);
+  HIP_TRY(c, hipGetLastError());
+  return ADMM_OK;
+}
 }  // namespace
 
 // Queues the chain objective kernels; dst (device, 2 doubles) receives the
@@ -1646,9 +1677,7 @@ static int chain_pairwise_enqueue(admm_ctx *c, double *slot) {
     c->swept_slot = 0;
     jobs = 2;
   }
-  hipLaunchKernelGGL(linear_reduce2_kernel, dim3(jobs), dim3(1024), 0, c->stream, a);
-  HIP_TRY(c, hipGetLastError());
-  return ADMM_OK;
+  return launch_reduce2(c, a, jobs);
 }
 
 // Sums the unary terms the last sweep left in d_chain_unary into their slot now.
@@ -1658,9 +1687,7 @@ static int settle_swept(admm_ctx *c) {
   a.dst[0] = c->d_obj_slots + 2 * (size_t)c->swept_slot; a.part[0] = c->d_chain_unary;
   a.n[0] = 2 * c->d.batch * (c->st.nrows + c->st.ncols);
   c->swept_slot = 0;
-  hipLaunchKernelGGL(linear_reduce2_kernel, dim3(1), dim3(1024), 0, c->stream, a);
-  HIP_TRY(c, hipGetLastError());
-  return ADMM_OK;
+  return launch_reduce2(c, a, 1);
 }
 
 // slot[0] = unary term of the current labels, gathered now.
