@@ -911,16 +911,21 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // copy while the chunk before it is already being fetched into registers
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // this wavefront's own back-pointer stores
   const int nchunks = Tpad / kChunk;
-  if constexpr (POTTS && CPW >= 4) {
-    // Four or more chains per wavefront: one lane per chain walks.  Lane tt
+  if constexpr (POTTS && CPW >= 2) {
+    // Two or more chains per wavefront: one lane per chain walks.  Lane tt
     // (= step tt of the chunk) cuts every chain's field out of the two masks
-    // and leaves  keep field | i1 << 16  in LDS, row = chain; lane q then reads
-    // its chain's row four steps at a time, walks it in registers
+    // and leaves  keep field | i1 << 16  (32 labels: the two as a pair of
+    // words) in LDS, row = chain; lane q then reads its chain's row 16 bytes at
+    // a time, walks it in registers
     //   x_{t-1} = bit x_t of keep ? x_t : i1
-    // and puts the labels where the words were, for the lanes to pick up step
-    // by step again.  Rows are padded by four dwords so that the 16-byte
-    // accesses of the walking lanes fall into different banks.
-    constexpr int RS = kChunk + 4;
+    // (a signed one-bit field extract and a bit-field insert per step) and puts
+    // the labels where the words were, for the lanes to pick up step by step
+    // again.  Rows are padded by four dwords so that the 16-byte accesses of the
+    // walking lanes fall into different banks.  With two chains of 32 labels
+    // this replaces a walk on the scalar unit that cost ten lane reads, lane
+    // writes and scalar instructions per step and wavefront.
+    constexpr int WPS = KP > 16 ? 2 : 1;  // words per step
+    constexpr int RS = kChunk * WPS + 4;
     static_assert(CPW * RS <= CPW * 16 * KP, "the staging rows fit the back-pointer buffer");
     uint32_t *stg = &s_bp[wib][0][0];
     uint32_t mr[4], mn[4], mf[4];  // this chunk, the next one, in flight
@@ -953,30 +958,51 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       if (ci > 1) load_chunk(mf, ci - 2);
 #pragma unroll
       for (int q = 0; q < CPW; q++) {
-        constexpr uint32_t FM = (1u << KP) - 1u;
+        constexpr uint32_t FM = KP >= 32 ? 0xFFFFFFFFu : (1u << (KP & 31)) - 1u;
         const uint32_t kf = ((q * KP < 32 ? mr[0] : mr[1]) >> ((q * KP) & 31)) & FM;
         const uint32_t ef = ((q * KP < 32 ? mr[2] : mr[3]) >> ((q * KP) & 31)) & FM;
         // at the chain's first node the masks are not used (whatever they hold
         // gives a label below KP)
         const uint32_t i1 = (uint32_t)__builtin_ctz(ef | (1u << (KP - 1)));
-        stg[q * RS + lane] = kf | (i1 << 16);
+        if constexpr (WPS == 2) *reinterpret_cast<uint2 *>(stg + q * RS + 2 * lane) = uint2{kf, i1};
+        else stg[q * RS + lane] = kf | (i1 << 16);
       }
       wave_lds_fence();
       if (lane < CPW) {
         uint4 *row = reinterpret_cast<uint4 *>(stg + lane * RS);
+        // x <- bit x of keep ? x : i1, branch-free: m = all ones or zero, then a bitwise select
+        auto step = [&](const uint32_t kw, const uint32_t i1) {
+          const int m = -(int)((kw >> cur) & 1u);
+          cur = (cur & m) | ((int)i1 & ~m);
+        };
+        // four steps (one or two 16-byte reads), labels written back to each step's first word
         auto walk4 = [&](auto g_c, const bool guarded) {
           constexpr int g = decltype(g_c)::value;
-          const uint4 w4 = row[g];
-          const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
           uint32_t o[4] = {0u, 0u, 0u, 0u};
+          if constexpr (WPS == 2) {
+            const uint4 hi = row[2 * g + 1], lo = row[2 * g];
+            const uint32_t kw[4] = {lo.x, lo.z, hi.x, hi.z}, iw[4] = {lo.y, lo.w, hi.y, hi.w};
 #pragma unroll
-          for (int e = 3; e >= 0; e--) {
-            if (!guarded || 4 * g + e < n) {
-              o[e] = (uint32_t)cur;
-              cur = ((w[e] >> cur) & 1u) ? cur : (int)(w[e] >> 16);
+            for (int e = 3; e >= 0; e--) {
+              if (!guarded || 4 * g + e < n) {
+                o[e] = (uint32_t)cur;
+                step(kw[e], iw[e]);
+              }
             }
+            row[2 * g] = uint4{o[0], 0u, o[1], 0u};
+            row[2 * g + 1] = uint4{o[2], 0u, o[3], 0u};
+          } else {
+            const uint4 w4 = row[g];
+            const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (int e = 3; e >= 0; e--) {
+              if (!guarded || 4 * g + e < n) {
+                o[e] = (uint32_t)cur;
+                step(w[e], w[e] >> 16);
+              }
+            }
+            row[g] = uint4{o[0], o[1], o[2], o[3]};
           }
-          row[g] = uint4{o[0], o[1], o[2], o[3]};
         };
         if (n == kChunk) {
           static_for<0, kChunk / 4>([&](auto r_c) { walk4(std::integral_constant<int, kChunk / 4 - 1 - decltype(r_c)::value>{}, false); });
@@ -990,7 +1016,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       wave_lds_fence();
       int xr[CPW];
 #pragma unroll
-      for (int q = 0; q < CPW; q++) xr[q] = (int)stg[q * RS + lane];
+      for (int q = 0; q < CPW; q++) xr[q] = (int)stg[q * RS + WPS * lane];
       wave_lds_fence();
       // labels out, and this chunk's terms of the linear objective
 #pragma unroll
@@ -1023,6 +1049,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     if (args.stamps && lane == 0) args.stamps[3 * (size_t)wave + 2] = __builtin_readcyclecounter();
     return;
   } else if constexpr (POTTS) {
+    // One chain of 64 labels per wavefront.
     // Lane tt holds the two masks of step tt of the chunk; the walk runs on the
     // scalar unit: x_{t-1} = x_t when bit x_t of the chain's field of keep is set,
     // else the lowest set bit of the chain's field of eq.  Labels are collected
@@ -1075,36 +1102,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
           curs[q] = ((keepm >> (q * KP + cu)) & 1) ? cu : i1;
         }
       };
-      if (n == kChunk && CPW == 2) {
-        // Two chains of 32 labels, one per half of the masks.  i1 of all 64
-        // steps at once (one vector instruction per chain), then per step and
-        // chain: record the label, test its bit of keep, keep it or take i1.
-        // Hand-written so that the walk costs the scalar unit two instructions
-        // per chain and step (it issues one per four cycles and SIMD, and that,
-        // not latency, is what the walk of four wavefronts per SIMD runs into).
-        const int vi0 = __builtin_ctz(mr[2] | 0x80000000u), vi1 = __builtin_ctz(mr[3] | 0x80000000u);
-#pragma unroll
-        for (int q = 0; q < CPW; q++) curs[q] = __builtin_amdgcn_readfirstlane(curs[q]);  // uniform already; pins it to a scalar register
-        asm volatile("s_nop 1");  // a vector instruction wrote the scalar the first lane write reads
-        static_for<0, kChunk>([&](auto r_c) {
-          constexpr int tt = kChunk - 1 - decltype(r_c)::value;
-          // named references: operands of an asm statement alone do not make
-          // a generic lambda capture a variable
-          int &x0 = xr[0], &x1 = xr[CPW - 1], &c0 = curs[0], &c1 = curs[CPW - 1];
-          int k0, k1, j0, j1;
-          const uint32_t m0 = mr[0], m1 = mr[1];
-          const int i0v = vi0, i1v = vi1;
-          asm volatile(
-              "v_readlane_b32 %[k0], %[m0], %[tt]\n\tv_readlane_b32 %[k1], %[m1], %[tt]\n\t"
-              "v_readlane_b32 %[j0], %[i0], %[tt]\n\tv_readlane_b32 %[j1], %[i1], %[tt]\n\t"
-              "v_writelane_b32 %[x0], %[c0], %[tt]\n\tv_writelane_b32 %[x1], %[c1], %[tt]\n\t"
-              "s_bitcmp1_b32 %[k0], %[c0]\n\ts_cselect_b32 %[c0], %[c0], %[j0]\n\t"
-              "s_bitcmp1_b32 %[k1], %[c1]\n\ts_cselect_b32 %[c1], %[c1], %[j1]"
-              : [x0] "+v"(x0), [x1] "+v"(x1), [c0] "+s"(c0), [c1] "+s"(c1), [k0] "=&s"(k0), [k1] "=&s"(k1), [j0] "=&s"(j0), [j1] "=&s"(j1)
-              : [m0] "v"(m0), [m1] "v"(m1), [i0] "v"(i0v), [i1] "v"(i1v), [tt] "n"(tt)
-              : "scc");
-        });
-      } else if (n == kChunk) {
+      if (n == kChunk) {
         static_for<0, kChunk>([&](auto r_c) { walk_step(std::integral_constant<int, kChunk - 1 - decltype(r_c)::value>{}); });
       } else {
         static_for<0, kChunk>([&](auto r_c) {

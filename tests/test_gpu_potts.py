@@ -158,6 +158,42 @@ def test_binary32_multipliers_on_request(monkeypatch):
     _check(R, C, k, _unaries(R, C, k, 78, quant=4), _potts(k, 0.5), iters=5)
 
 
+def test_objectives_of_a_large_batch():
+    # 66560 per-half-chain terms: above the size from which the objective sums run in two stages
+    import admm_amd as A
+    from oracle import oracle as O
+    R, C, k, B = 128, 128, 8, 130
+    W = _potts(k, 0.5)
+    rng = np.random.default_rng(123)
+    un = rng.random((B * R * C, k), dtype=np.float32)
+    g = A.Grid()
+    g.SetPartitioner(A.ROW)
+    g.SetPenalties(0.5, 1.0)
+    g.SetGlobalInfo(R, C, k, batch=B)
+    g.Load(un, W)
+    g.InitOptimization()
+    queued = []
+    for it in range(3):
+        g.Compute(); g.Communicate(); g.Update()
+        g.ObjectiveEnqueue(1 + it)
+    g.Synchronize()
+    queued = g.ObjectiveRead(1, 3)
+    lin = g.ComputeLinearObj()
+    primal, dual = g.Objective(dual=True)
+    g.close()
+    ref = np.zeros((3, 3))
+    for b in range(B):
+        o = O.ChainOracle(R, C, k, un[b * R * C:(b + 1) * R * C], W)
+        o.init()
+        for it in range(3):
+            o.compute(); o.update()
+            ref[it] += np.array(o.objective())
+    for it in range(3):
+        assert abs(queued[it] - ref[it][2]) <= 1e-9 * abs(ref[it][2]), (it, queued[it], ref[it][2])
+    for x, y in ((primal, ref[2][0]), (dual, ref[2][1]), (lin, ref[2][2])):
+        assert abs(x - y) <= 1e-9 * abs(y), (x, y)
+
+
 @pytest.mark.parametrize("w", [0.0, 0.25, 1e-30, 1e30, float("inf")])
 def test_potts_weights_with_ties(w):
     # quantised unaries and a weight on the same lattice (or zero, or absorbing): ties between
