@@ -596,6 +596,14 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       xown = s_x[wib][cs][tt0 + s];
       xoth = s_xo[wib][cs][tt0 + s];
     }
+    // Potts step on int16 counts: the shell of two steps at a time (PAIRED)
+    constexpr bool PAIRED = POTTS && LAM16 && GPB % 2 == 0;
+    int xown1 = -1, xoth1 = -1;  // labels of the step after the current one
+    float th_pair = INF;         // adjusted unary of the odd step, worked out with the even one
+    if constexpr (PAIRED) {
+      xown1 = s_x[wib][cs][tt0 + 1];
+      xoth1 = s_xo[wib][cs][tt0 + 1];
+    }
     static_for<0, GPB>([&](auto j_c) {
       constexpr int j = decltype(j_c)::value;
       const int tg = tb + j * NS;
@@ -605,7 +613,43 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       const float lam_in = LAM16 ? (float)n_in * shpen : __uint_as_float(__float_as_uint(plam[j]) ^ lam_sign);
       const unsigned goff = soff0 + (unsigned)tg * sstep;  // uniform
       float th_own = INF;
-      if (DUAL) {
+      if constexpr (PAIRED) {
+        // The shell is elementwise, so steps j and j + 1 go through it together on
+        // packed binary32 instructions.  With d = [x_own = b] - [x_other = b] and
+        // m = +-n + d (the set's sign on the count):
+        //   lambda + penalty (mu - m) = m * penalty/2,  penalty (mu - m) = d * penalty/2,
+        // both exact, hence the same bits as the sums of Tree.cpp:70 and :85-86.
+        // A step past the chain's end has labels -1 (d = 0, nothing added to the
+        // unary sum), is never stored and its value never used.
+        if constexpr (j % 2 == 0) {
+          typedef float f2 __attribute__((ext_vector_type(2)));
+          const int sgn = lam_sign ? -1 : 1;
+          const int d0 = (int)(xown == b) - (int)(xoth == b), d1 = (int)(xown1 == b) - (int)(xoth1 == b);
+          // m = n * sgn + d in one instruction (the counts are 16-bit; left to itself the
+          // compiler takes a 64-bit multiply-add for it)
+          int m0, m1;
+          asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(m0) : "v"(n_in), "s"(sgn), "v"(d0));
+          asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(m1) : "v"(__float_as_int(plam[j + 1])), "s"(sgn), "v"(d1));
+          const f2 hp2 = {hpen, hpen}, rho2 = {rho, rho};
+          const f2 la2 = f2{(float)m0, (float)m1} * hp2;   // Tree.cpp:70
+          const f2 p2 = f2{(float)d0, (float)d1} * hp2;
+          const f2 th2 = {th_in, pth[j + 1]};
+          const f2 own2 = rho2 * (th2 + la2) + p2;          // Tree.cpp:85-86
+          th_own = own2.x;
+          th_pair = own2.y;
+          float sel0 = (xown == b) ? th_in : 0.0f, sel1 = (xown1 == b) ? pth[j + 1] : 0.0f;
+          asm("" : "+v"(sel0), "+v"(sel1));
+          unary_acc += (double)sel0;
+          unary_acc += (double)sel1;
+          // (stored by the sets that keep their own array, where sgn = 1 and m is the new count)
+          if (FULL || tg < T)
+            __builtin_amdgcn_raw_buffer_store_b16((short)m0, lamo_rs, lane_off_st, soff0_l + (unsigned)tg * sstep_l, 0);
+          if (FULL || tg + 1 < T)
+            __builtin_amdgcn_raw_buffer_store_b16((short)m1, lamo_rs, lane_off_st, soff0_l + (unsigned)(tg + 1) * sstep_l, 0);
+        } else {
+          th_own = th_pair;
+        }
+      } else if (DUAL) {
         th_own = th_in + lam_in;
       } else if (glive) {
         // p = penalty * (mu - m) = -(penalty * (m - mu)), exactly
@@ -648,7 +692,14 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
           }
         }
         if (u == NS - 1) {
-          if (!DUAL && j + 1 < GPB) {
+          if constexpr (PAIRED) {
+            if (j % 2 == 1 && j + 1 < GPB) {
+              xown = s_x[wib][cs][tt0 + j + 1];
+              xoth = s_xo[wib][cs][tt0 + j + 1];
+              xown1 = s_x[wib][cs][tt0 + j + 2];
+              xoth1 = s_xo[wib][cs][tt0 + j + 2];
+            }
+          } else if (!DUAL && j + 1 < GPB) {
             xown = s_x[wib][cs][tt0 + (j + 1) * NS + s];
             xoth = s_xo[wib][cs][tt0 + (j + 1) * NS + s];
           }
