@@ -18,6 +18,7 @@ COMM_ID_BYTES = 128
 # every symbol include/admm_hip.h declares
 EXPORTS = [
     "admm_create", "admm_destroy", "admm_last_error", "admm_upload_unaries",
+    "admm_upload_unaries_rows", "admm_upload_unaries_cols",
     "admm_upload_pairwise", "admm_init", "admm_compute", "admm_communicate",
     "admm_communicate_group", "admm_exchange_counts", "admm_exchange_pack_host",
     "admm_exchange_unpack_host", "admm_update",
@@ -26,7 +27,7 @@ EXPORTS = [
     "admm_state_size", "admm_partition", "admm_strip_info", "admm_edge_local_info", "admm_edge_local_vertices", "admm_edge_plan",
     "admm_comm_get_unique_id",
     "admm_comm_init", "admm_lcg_fill", "admm_grid_edges", "admm_profile_reset",
-    "admm_profile_read", "admm_sweep_kernel_info", "admm_device_count", "admm_version",
+    "admm_profile_read", "admm_sweep_kernel_info", "admm_sweep_kernel_name", "admm_device_count", "admm_version",
 ]
 
 
@@ -61,6 +62,8 @@ def _load():
         "admm_destroy": (C.c_int, [vp]),
         "admm_last_error": (C.c_char_p, [vp]),
         "admm_upload_unaries": (C.c_int, [vp, fp]),
+        "admm_upload_unaries_rows": (C.c_int, [vp, C.c_int, C.c_int, fp]),
+        "admm_upload_unaries_cols": (C.c_int, [vp, C.c_int, C.c_int, fp]),
         "admm_upload_pairwise": (C.c_int, [vp, fp, C.c_int]),
         "admm_init": (C.c_int, [vp]),
         "admm_compute": (C.c_int, [vp]),
@@ -92,6 +95,7 @@ def _load():
         "admm_profile_reset": (C.c_int, [vp, C.c_int]),
         "admm_profile_read": (C.c_int, [vp, dp, C.POINTER(C.c_int)]),
         "admm_sweep_kernel_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "admm_sweep_kernel_name": (C.c_int, [vp, C.c_char_p, C.c_int]),
         "admm_device_count": (C.c_int, []),
         "admm_version": (C.c_char_p, []),
     }

@@ -34,6 +34,13 @@ struct admm_ctx {
   std::string err;
   hipStream_t stream = nullptr;
   bool have_unary = false, have_pair = false, inited = false;
+  // chain solver: th_r / th_c hold the per-copy shares already (admm_init scales
+  // the uploaded unaries in place), so an admm_init that follows a new pairwise
+  // table alone must not scale them a second time
+  bool theta_scaled = false;
+  // chain solver, unaries uploaded a share at a time: which rows of the row
+  // strip / of the column strip have arrived since the last restart
+  std::vector<uint8_t> seen_r, seen_c;
   std::vector<void *> allocs;
 
   // ---- edge solver ----
@@ -111,6 +118,11 @@ struct admm_ctx {
   float *sendbuf_mu = nullptr, *recvbuf_mu = nullptr;  // ADMM_EXCHANGE_DENSE: the same blocks as float k-vectors
   std::vector<float> h_unary_stage;
 
+  // staging of the download calls (decoded labels, consensus vectors, widened
+  // state): grown on demand, kept between calls
+  void *d_stage = nullptr;
+  size_t stage_bytes = 0;
+
   ncclComm_t comm = nullptr;
   hipEvent_t ev_packed = nullptr, ev_pulled = nullptr;  // admm_communicate_group
 
@@ -148,6 +160,38 @@ int fail(admm_ctx *c, int code, const char *fmt, ...) {
                   __FILE__, __LINE__);                                                \
   } while (0)
 
+// A group of RCCL point-to-point calls.  ncclGroupStart is always matched by
+// ncclGroupEnd, also when a call inside fails (the thread must not be left
+// inside an open group): the first error is remembered and end() reports it.
+class NcclGroup {
+  admm_ctx *c_;
+  ncclResult_t first_ = ncclSuccess;
+  const char *what_ = "";
+  bool open_ = false;
+
+ public:
+  explicit NcclGroup(admm_ctx *c) : c_(c) {
+    first_ = ncclGroupStart();
+    open_ = first_ == ncclSuccess;
+    if (!open_) what_ = "ncclGroupStart";
+  }
+  NcclGroup(const NcclGroup &) = delete;
+  NcclGroup &operator=(const NcclGroup &) = delete;
+  bool ok() const { return first_ == ncclSuccess; }
+  void add(ncclResult_t r, const char *what) {
+    if (first_ == ncclSuccess && r != ncclSuccess) { first_ = r; what_ = what; }
+  }
+  int end() {
+    if (open_) {
+      open_ = false;
+      const ncclResult_t r = ncclGroupEnd();
+      if (first_ == ncclSuccess && r != ncclSuccess) { first_ = r; what_ = "ncclGroupEnd"; }
+    }
+    return first_ == ncclSuccess ? ADMM_OK : fail(c_, ADMM_E_COMM, "%s failed: %s", what_, ncclGetErrorString(first_));
+  }
+  ~NcclGroup() { if (open_) (void)ncclGroupEnd(); }
+};
+
 template <typename T>
 int dev_alloc(admm_ctx *c, T **p, size_t n) {
   void *q = nullptr;
@@ -158,11 +202,32 @@ int dev_alloc(admm_ctx *c, T **p, size_t n) {
   *p = (T *)q;
   // ADMM_POISON=<byte> (debugging knob): every allocation starts filled with that byte, so a read
   // of memory nothing initialised shows up on every run and not only when the memory was dirty
-  static const char *poison = getenv("ADMM_POISON");
+  const char *poison = getenv("ADMM_POISON");
   if (poison) {
     (void)hipMemset(q, atoi(poison) & 0xFF, std::max<size_t>(n, 1) * sizeof(T));
     (void)hipDeviceSynchronize();
   }
+  return ADMM_OK;
+}
+
+// Device staging of at least `bytes` for a download call; kept by the context,
+// so only a call that needs more than any call before it allocates.
+int stage_buf(admm_ctx *c, void **p, size_t bytes) {
+  if (bytes > c->stage_bytes) {
+    if (c->d_stage) {
+      (void)hipStreamSynchronize(c->stream);
+      (void)hipFree(c->d_stage);
+      c->d_stage = nullptr;
+      c->stage_bytes = 0;
+    }
+    const hipError_t e = hipMalloc(&c->d_stage, bytes);
+    if (e != hipSuccess) {
+      c->d_stage = nullptr;
+      return fail(c, ADMM_E_NOMEM, "hipMalloc of %zu bytes of staging failed: %s", bytes, hipGetErrorString(e));
+    }
+    c->stage_bytes = bytes;
+  }
+  *p = c->d_stage;
   return ADMM_OK;
 }
 
@@ -215,16 +280,18 @@ SweepShape pick_shape(int KP, long long nchains) {
   return {KP, NS};
 }
 
+// Template arguments the general kernel is built with for a lane layout.
+// GPB: prefetch distance in load groups of NS steps; 64 source labels per lane
+// need the registers of a 2-wavefront-per-SIMD allocation.  MINW: arg-min of
+// 32+ candidates per lane, or a split chain (scarce chains, so occupancy is not
+// the limit): room for 256 registers (8 or 16 labels packed several chains to a
+// wavefront spill at 128 registers).
+constexpr int sweep_gpb(int KP, int NS) { return (NS >= 4 || KP / NS >= 64) ? 4 : 8; }
+constexpr int sweep_minw(int KP, int NS) { return (KP / NS >= 32 || NS > 1) ? 2 : (KP >= 8 ? 3 : 4); }
+
 template <int KP, int NS, bool DUAL>
 void launch_sweep_t(const ChainArgs &a, int blocks, hipStream_t s) {
-  // prefetch distance GPB groups of NS steps; 64 source labels per lane need
-  // the registers of a 2-wavefront-per-SIMD allocation
-  constexpr int GPB = (NS >= 4 || KP / NS >= 64) ? 4 : 8;
-  // arg-min of 32+ candidates per lane, or a split chain (scarce chains, so
-  // occupancy is not the limit): room for 256 registers
-  // (8 or 16 labels packed several chains to a wavefront spill at 128 registers)
-  constexpr int MINW = (KP / NS >= 32 || NS > 1) ? 2 : (KP >= 8 ? 3 : 4);
-  hipLaunchKernelGGL((chain_sweep_kernel<KP, NS, GPB, MINW, DUAL>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+  hipLaunchKernelGGL((chain_sweep_kernel<KP, NS, sweep_gpb(KP, NS), sweep_minw(KP, NS), DUAL>), dim3(blocks), dim3(kChainBlock), 0, s, a);
 }
 
 template <int KP>
@@ -740,6 +807,11 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
     const long long span_row = (((long long)d.cols + 1) / 2 + 130) * d.k + 64LL * d.cols * d.k;
     if (span_col >= (1LL << 30) || span_row >= (1LL << 30))
       return fail(nullptr, ADMM_E_ARG, "grid too large for the sweep's 32-bit offsets: (rows / 2 + 130) * cols * k must stay below 2^30");
+    // a batch: the chains that share a wavefront may belong to two consecutive
+    // grids, so the lane offsets also span one whole grid
+    const long long grid_el = (long long)d.rows * d.cols * d.k;
+    if (d.batch > 1 && (span_col + grid_el >= (1LL << 30) || span_row + grid_el >= (1LL << 30)))
+      return fail(nullptr, ADMM_E_ARG, "grids of a batch too large for the sweep's 32-bit offsets: rows * cols * k plus (rows / 2 + 130) * cols * k must stay below 2^30");
     if (d.nranks > 1 && d.batch != 1) return fail(nullptr, ADMM_E_ARG, "strips (nranks > 1) need batch == 1; shard a batch by grids instead");
     if (d.exchange != ADMM_EXCHANGE_LABELS && d.exchange != ADMM_EXCHANGE_DENSE)
       return fail(nullptr, ADMM_E_ARG, "unknown exchange mode %d", d.exchange);
@@ -887,6 +959,7 @@ int admm_destroy(admm_ctx *c) {
   if (c->ev_pulled) (void)hipEventDestroy(c->ev_pulled);
   for (auto &pr : c->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (void *p : c->allocs) (void)hipFree(p);
+  if (c->d_stage) (void)hipFree(c->d_stage);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return ADMM_OK;
@@ -972,11 +1045,61 @@ int admm_upload_unaries(admm_ctx *c, const float *unary) {
                                   sizeof(float) * c->st.ncols * k, d.rows, hipMemcpyHostToDevice, c->stream));
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->seen_r.assign((size_t)c->st.nrows, 1);
+    c->seen_c.assign((size_t)d.rows, 1);
   }
   c->have_unary = true;
+  c->theta_scaled = false;
   c->inited = false;
   return ADMM_OK;
 }
+
+// A share of the unaries of the chain solver.  side 0: whole grid rows of the
+// row strip, [nrows][cols][k]; side 1: the column strip's part of grid rows,
+// [nrows][strip cols][k].
+static int upload_share(admm_ctx *c, int side, int row0, int nrows, const float *data) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!is_chain(c)) return fail(c, ADMM_E_STATE, "shares of the unaries are a chain-solver call");
+  if (c->d.batch != 1) return fail(c, ADMM_E_ARG, "shares of the unaries need batch == 1");
+  if (!data && nrows > 0) return fail(c, ADMM_E_ARG, "null unary array");
+  const admm_desc &d = c->d;
+  const int lo = side == 0 ? c->st.row0 : 0, hi = side == 0 ? c->st.row0 + c->st.nrows : d.rows;
+  if (nrows < 0 || row0 < lo || (long long)row0 + nrows > hi)
+    return fail(c, ADMM_E_ARG, "rows [%d, %d) lie outside this strip's rows [%d, %d)", row0, row0 + nrows, lo, hi);
+  if ((rc = flush_pending(c))) return rc;  // a queued objective still needs the old unaries
+  if (c->theta_scaled || c->inited || c->seen_r.size() != (size_t)c->st.nrows || c->seen_c.size() != (size_t)d.rows) {
+    // first share after a solve (or ever): everything has to arrive again
+    c->seen_r.assign((size_t)c->st.nrows, 0);
+    c->seen_c.assign((size_t)d.rows, 0);
+    c->theta_scaled = false;
+    c->inited = false;
+    c->have_unary = false;
+  }
+  const size_t k = d.k;
+  if (side == 0) {
+    const size_t w = (size_t)d.cols * k;
+    if (nrows > 0) HIP_TRY(c, h2d_sync(c, c->th_r + (size_t)(row0 - c->st.row0) * w, data, sizeof(float) * w * nrows));
+    for (int r = 0; r < nrows; r++) c->seen_r[(size_t)(row0 - c->st.row0 + r)] = 1;
+    // one strip: the column chains read the same array
+    if (c->one_strip()) for (int r = 0; r < nrows; r++) c->seen_c[(size_t)(row0 + r)] = 1;
+  } else {
+    if (!c->one_strip()) {
+      const size_t w = (size_t)c->st.ncols * k;
+      if (nrows > 0 && w > 0) HIP_TRY(c, h2d_sync(c, c->th_c + (size_t)row0 * w, data, sizeof(float) * w * nrows));
+    }
+    // (one strip: th_c is th_r and the rows call fills it; nothing to copy)
+    if (!c->one_strip()) for (int r = 0; r < nrows; r++) c->seen_c[(size_t)(row0 + r)] = 1;
+  }
+  bool all = true;
+  for (uint8_t v : c->seen_r) all = all && v;
+  for (uint8_t v : c->seen_c) all = all && v;
+  c->have_unary = all;
+  return ADMM_OK;
+}
+
+int admm_upload_unaries_rows(admm_ctx *c, int row0, int nrows, const float *rows) { return upload_share(c, 0, row0, nrows, rows); }
+int admm_upload_unaries_cols(admm_ctx *c, int row0, int nrows, const float *cols) { return upload_share(c, 1, row0, nrows, cols); }
 
 int admm_upload_pairwise(admm_ctx *c, const float *table, int per_edge) {
   int rc = check_ctx(c);
@@ -1030,7 +1153,7 @@ __global__ void chain_init_w_kernel(float *Wsplit, float *Wt, float *WsplitT, fl
 int admm_init(admm_ctx *c) {
   int rc = check_ctx(c);
   if (rc) return rc;
-  if (!c->have_unary || !c->have_pair) return fail(c, ADMM_E_STATE, "upload unaries and the pairwise table before admm_init");
+  if (!c->have_unary || !c->have_pair) return fail(c, ADMM_E_STATE, "upload unaries (every row of this strip's shares) and the pairwise table before admm_init");
   if ((rc = flush_pending(c))) return rc;  // a queued objective still needs the old labels
   const admm_desc &d = c->d;
   hipStream_t s = c->stream;
@@ -1087,7 +1210,10 @@ int admm_init(admm_ctx *c) {
     if (c->inited) return fail(c, ADMM_E_STATE, "admm_init was already called; upload the unaries again to restart");
     const long long k = d.k;
     const long long nrow = (long long)d.batch * c->st.nrows * d.cols, ncol = (long long)d.batch * d.rows * c->st.ncols;
-    hipLaunchKernelGGL(chain_init_theta_kernel, dim3(grid_for(nrow * k, 256)), dim3(256), 0, s, c->th_r, nrow * k, d.rho);
+    // the shares of the unaries are worked out in place, once per upload: a
+    // restart with a new pairwise table alone finds them in place already
+    const bool scale = !c->theta_scaled;
+    if (scale) hipLaunchKernelGGL(chain_init_theta_kernel, dim3(grid_for(nrow * k, 256)), dim3(256), 0, s, c->th_r, nrow * k, d.rho);
     HIP_TRY(c, hipMemsetAsync(c->lam_r, 0, sizeof(float) * nrow * k, s));
     HIP_TRY(c, hipMemsetAsync(c->lam_c, 0, sizeof(float) * ncol * k, s));
     // -1 in every label, whatever its width
@@ -1100,7 +1226,7 @@ int admm_init(admm_ctx *c) {
       HIP_TRY(c, hipMemsetAsync(c->xo_c, 0xFF, sizeof(label_t) * ncol, s));
     }
     if (d.nranks > 1) {
-      hipLaunchKernelGGL(chain_init_theta_kernel, dim3(grid_for(ncol * k, 256)), dim3(256), 0, s, c->th_c, ncol * k, d.rho);
+      if (scale) hipLaunchKernelGGL(chain_init_theta_kernel, dim3(grid_for(ncol * k, 256)), dim3(256), 0, s, c->th_c, ncol * k, d.rho);
       hipLaunchKernelGGL(fill_int_kernel, dim3(grid_for(nrow, 256)), dim3(256), 0, s, c->xcolT_r, nrow, -1);
       hipLaunchKernelGGL(fill_int_kernel, dim3(grid_for(ncol, 256)), dim3(256), 0, s, c->xrow_c, ncol, -1);
     }
@@ -1129,6 +1255,7 @@ int admm_init(admm_ctx *c) {
   }
   HIP_TRY(c, hipStreamSynchronize(s));
   c->inited = true;
+  if (is_chain(c)) c->theta_scaled = true;
   c->lin_valid = false;
   return ADMM_OK;
 }
@@ -1288,15 +1415,14 @@ int admm_communicate(admm_ctx *c) {
   if (!is_chain(c)) {
     // CommunicateByEdge (Grid.cpp:1639-1663): one message to and one from every neighbour
     if ((rc = edge_pack_partials(c))) return rc;
-    NCCL_TRY(c, ncclGroupStart());
+    NcclGroup grp(c);
     for (size_t q = 0; q < c->nb_rank.size(); q++) {
       const size_t off = (size_t)c->nb_off[q] * d.k, n = (size_t)(c->nb_off[q + 1] - c->nb_off[q]) * d.k;
       if (n == 0) continue;
-      NCCL_TRY(c, ncclSend(c->d_sendv + off, n, ncclFloat, c->nb_rank[q], c->comm, c->stream));
-      NCCL_TRY(c, ncclRecv(c->d_recvv + off, n, ncclFloat, c->nb_rank[q], c->comm, c->stream));
+      grp.add(ncclSend(c->d_sendv + off, n, ncclFloat, c->nb_rank[q], c->comm, c->stream), "ncclSend");
+      grp.add(ncclRecv(c->d_recvv + off, n, ncclFloat, c->nb_rank[q], c->comm, c->stream), "ncclRecv");
     }
-    NCCL_TRY(c, ncclGroupEnd());
-    return ADMM_OK;
+    return grp.end();
   }
   hipStream_t s = c->stream;
   const int G = d.nranks;
@@ -1319,15 +1445,17 @@ int admm_communicate(admm_ctx *c) {
     if ((long long)nc * p.nr[h] > 0)
       HIP_TRY(c, hipMemcpyAsync(w.recv_b + (size_t)p.c0[h] * nr * m, send_b + p.off_b[h] * m, (size_t)nc * p.nr[h] * m * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
   }
-  NCCL_TRY(c, ncclGroupStart());
-  for (int h = 0; h < G; h++) {
-    if (h == d.rank) continue;
-    if ((long long)nr * p.nc[h] > 0) NCCL_TRY(c, ncclSend(send_a + p.off_a[h] * m, (size_t)nr * p.nc[h] * m, ncclInt32, h, c->comm, s));
-    if ((long long)p.nr[h] * nc > 0) NCCL_TRY(c, ncclRecv(w.recv_a + (size_t)p.r0[h] * nc * m, (size_t)p.nr[h] * nc * m, ncclInt32, h, c->comm, s));
-    if ((long long)nc * p.nr[h] > 0) NCCL_TRY(c, ncclSend(send_b + p.off_b[h] * m, (size_t)nc * p.nr[h] * m, ncclInt32, h, c->comm, s));
-    if ((long long)p.nc[h] * nr > 0) NCCL_TRY(c, ncclRecv(w.recv_b + (size_t)p.c0[h] * nr * m, (size_t)p.nc[h] * nr * m, ncclInt32, h, c->comm, s));
+  {
+    NcclGroup grp(c);
+    for (int h = 0; h < G; h++) {
+      if (h == d.rank) continue;
+      if ((long long)nr * p.nc[h] > 0) grp.add(ncclSend(send_a + p.off_a[h] * m, (size_t)nr * p.nc[h] * m, ncclInt32, h, c->comm, s), "ncclSend");
+      if ((long long)p.nr[h] * nc > 0) grp.add(ncclRecv(w.recv_a + (size_t)p.r0[h] * nc * m, (size_t)p.nr[h] * nc * m, ncclInt32, h, c->comm, s), "ncclRecv");
+      if ((long long)nc * p.nr[h] > 0) grp.add(ncclSend(send_b + p.off_b[h] * m, (size_t)nc * p.nr[h] * m, ncclInt32, h, c->comm, s), "ncclSend");
+      if ((long long)p.nc[h] * nr > 0) grp.add(ncclRecv(w.recv_b + (size_t)p.c0[h] * nr * m, (size_t)p.nc[h] * nr * m, ncclInt32, h, c->comm, s), "ncclRecv");
+    }
+    if ((rc = grp.end())) return rc;
   }
-  NCCL_TRY(c, ncclGroupEnd());
   return unpack_received(c);
 }
 
@@ -1848,6 +1976,20 @@ __global__ void widen_labels_kernel(int *__restrict__ out, const label_t *__rest
 }  // namespace
 }  // extern "C++"
 
+// Decoded labelling of this strip into `stage` (device, `total` ints), then to the host.
+static int decode_labels_into(admm_ctx *c, int *stage, int32_t *labels, long long total) {
+  if (c->one_strip())
+    hipLaunchKernelGGL(chain_decode_kernel<label_t>, dim3(grid_for(total, 256)), dim3(256), 0, c->stream, stage, c->xrow_r,
+                       c->xcolT_c, c->st.nrows, c->d.cols, total);
+  else
+    hipLaunchKernelGGL(chain_decode_kernel<int>, dim3(grid_for(total, 256)), dim3(256), 0, c->stream, stage, c->xrow_r,
+                       c->xcolT_r, c->st.nrows, c->d.cols, total);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(labels, stage, sizeof(int) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ADMM_OK;
+}
+
 int admm_download_labels(admm_ctx *c, int32_t *labels) {
   int rc = check_ctx(c);
   if (rc) return rc;
@@ -1856,19 +1998,9 @@ int admm_download_labels(admm_ctx *c, int32_t *labels) {
   if (!labels) return fail(c, ADMM_E_ARG, "null output");
   const long long total = (long long)c->d.batch * c->st.nrows * c->d.cols;
   if (total == 0) return ADMM_OK;
-  int *tmp = nullptr;
-  HIP_TRY(c, hipMalloc((void **)&tmp, sizeof(int) * total));
-  if (c->one_strip())
-    hipLaunchKernelGGL(chain_decode_kernel<label_t>, dim3(grid_for(total, 256)), dim3(256), 0, c->stream, tmp, c->xrow_r,
-                       c->xcolT_c, c->st.nrows, c->d.cols, total);
-  else
-    hipLaunchKernelGGL(chain_decode_kernel<int>, dim3(grid_for(total, 256)), dim3(256), 0, c->stream, tmp, c->xrow_r,
-                       c->xcolT_r, c->st.nrows, c->d.cols, total);
-  hipError_t e = hipMemcpyAsync(labels, tmp, sizeof(int) * total, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(tmp);
-  HIP_TRY(c, e);
-  return ADMM_OK;
+  void *stage = nullptr;
+  if ((rc = stage_buf(c, &stage, sizeof(int) * (size_t)total))) return rc;
+  return decode_labels_into(c, (int *)stage, labels, total);
 }
 
 int admm_download_consensus(admm_ctx *c, float *out) {
@@ -1884,15 +2016,14 @@ int admm_download_consensus(admm_ctx *c, float *out) {
   // the k-vectors exist only here: built from the labels on request
   const size_t n = (size_t)c->d.batch * c->st.nrows * c->d.cols * c->d.k;
   if (n == 0) return ADMM_OK;
-  float *tmp = nullptr;
-  HIP_TRY(c, hipMalloc((void **)&tmp, sizeof(float) * n));
+  void *stage = nullptr;
+  if ((rc = stage_buf(c, &stage, sizeof(float) * n))) return rc;
+  float *tmp = (float *)stage;
   rc = c->one_strip() ? chain_consensus<label_t>(c, tmp, c->xrow_r, c->xcolT_c, c->st.nrows, c->d.cols)
                       : chain_consensus<int>(c, tmp, c->xrow_r, c->xcolT_r, c->st.nrows, c->d.cols);
-  hipError_t e = rc ? hipSuccess : hipMemcpyAsync(out, tmp, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(tmp);
   if (rc) return rc;
-  HIP_TRY(c, e);
+  HIP_TRY(c, hipMemcpyAsync(out, tmp, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return ADMM_OK;
 }
 
@@ -1931,7 +2062,7 @@ int admm_download_state(admm_ctx *c, int which, float *out) {
       case 4: src = c->d_mu_edge; break;
       case 5: src = c->d_pot_edge; break;
       case 2:
-        HIP_TRY(c, hipMalloc(&tmp, sizeof(float) * n));
+        if ((rc = stage_buf(c, &tmp, sizeof(float) * n))) return rc;
         hipLaunchKernelGGL(edge_gather_m_kernel, dim3(grid_for((long long)n, 256)), dim3(256), 0, c->stream,
                            (float *)tmp, c->d_m_vert, c->d_edges, c->E, c->d.k);
         src = tmp;
@@ -1941,7 +2072,7 @@ int admm_download_state(admm_ctx *c, int which, float *out) {
     switch (which) {
       case 10: case 11:
         if (c->lam16) {
-          HIP_TRY(c, hipMalloc(&tmp, sizeof(float) * n));
+          if ((rc = stage_buf(c, &tmp, sizeof(float) * n))) return rc;
           hipLaunchKernelGGL(widen_multipliers_kernel, dim3(grid_for((long long)n, 256)), dim3(256), 0, c->stream,
                              (float *)tmp, reinterpret_cast<const int16_t *>((which == 10 || c->lam_shared()) ? c->lam_r : c->lam_c),
                              (long long)n, c->d.penalty * 0.5f);
@@ -1952,24 +2083,23 @@ int admm_download_state(admm_ctx *c, int which, float *out) {
         break;
       case 12: src = c->th_r; break;
       case 13:
-        HIP_TRY(c, hipMalloc(&tmp, sizeof(int) * n));
+        if ((rc = stage_buf(c, &tmp, sizeof(int) * n))) return rc;
         hipLaunchKernelGGL(widen_labels_kernel, dim3(grid_for((long long)n, 256)), dim3(256), 0, c->stream,
                            (int *)tmp, c->xrow_r, (long long)n);
         src = tmp;
         break;
       case 14:
         // stored chain-major ([col][row]); hand it out as [row][col]
-        HIP_TRY(c, hipMalloc(&tmp, sizeof(int) * n));
+        if ((rc = stage_buf(c, &tmp, sizeof(int) * n))) return rc;
         hipLaunchKernelGGL(transpose_int_kernel, dim3(grid_for((long long)n, 256)), dim3(256), 0, c->stream,
                            (int *)tmp, c->xcolT_c, c->d.rows, c->st.ncols, (long long)n);
         src = tmp;
         break;
     }
   }
-  hipError_t e = hipMemcpyAsync(out, src, 4 * n, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  if (tmp) (void)hipFree(tmp);
-  HIP_TRY(c, e);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(out, src, 4 * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   // the column multipliers are kept as the row ones negated (never -0: a sum
   // that starts from +0 cannot round to it, so 0 - x restores the exact bits)
   if (is_chain(c) && which == 11 && c->lam_shared())
@@ -1995,7 +2125,16 @@ int admm_comm_init(admm_ctx *c, const void *id) {
   if (c->comm) return fail(c, ADMM_E_STATE, "communicator already initialised");
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
-  NCCL_TRY(c, ncclCommInitRank(&c->comm, c->d.nranks, u, c->d.rank));
+  ncclComm_t comm = nullptr;
+  const ncclResult_t r = ncclCommInitRank(&comm, c->d.nranks, u, c->d.rank);
+  if (r != ncclSuccess) {
+    // Whatever a failed bootstrap left in `comm` is not a communicator: it is
+    // dropped here, never handed to ncclCommDestroy (which frees it a second
+    // time and aborts the process at teardown).
+    c->comm = nullptr;
+    return fail(c, ADMM_E_COMM, "ncclCommInitRank(nranks=%d, rank=%d) failed: %s", c->d.nranks, c->d.rank, ncclGetErrorString(r));
+  }
+  c->comm = comm;
   return ADMM_OK;
 }
 
@@ -2019,6 +2158,21 @@ int admm_sweep_kernel_info(admm_ctx *c, int *label_lanes, int *lanes_per_label, 
   if (label_lanes) *label_lanes = sh.KP;
   if (lanes_per_label) *lanes_per_label = sh.NS;
   if (potts_out) *potts_out = potts ? 1 : 0;
+  return ADMM_OK;
+}
+
+int admm_sweep_kernel_name(admm_ctx *c, char *buf, int len) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!is_chain(c)) return fail(c, ADMM_E_ARG, "the edge solver has no sweep kernel");
+  if (!c->inited) return fail(c, ADMM_E_STATE, "admm_sweep_kernel_name before admm_init");
+  if (!buf || len < 1) return fail(c, ADMM_E_ARG, "null buffer");
+  SweepShape sh = pick_shape(c->KP, (long long)c->d.batch * ((long long)c->st.nrows + c->st.ncols));
+  const bool potts = potts_chosen(c, sh);
+  if (potts)
+    snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, 1, 8, 4, false, true, %s>", sh.KP, c->lam16 ? "true" : "false");
+  else
+    snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, %d, %d, %d, false, false, false>", sh.KP, sh.NS, sweep_gpb(sh.KP, sh.NS), sweep_minw(sh.KP, sh.NS));
   return ADMM_OK;
 }
 

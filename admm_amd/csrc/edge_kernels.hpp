@@ -179,7 +179,9 @@ __global__ void edge_consensus_kernel(float *__restrict__ m_vert, const float *_
     float s = 0.0f;
     for (int q = b; q < en; q++) s += mu_node[(long long)inc[q] * k + l];
     const int cnt = en - b;
-    m_vert[idx] = s / cnt;
+    // a vertex no edge touches (possible in a caller's graph; the reference's vertex
+    // sets hold endpoints only, Grid.cpp:815-856) keeps the uniform vector admm_init wrote
+    if (cnt > 0) m_vert[idx] = s / cnt;
   }
 }
 

@@ -47,8 +47,14 @@ void Grid::Load(const std::string &fname) {
   if (numEdgePotentials != k * k) throw AdmmError(ADMM_E_ARG, "numEdgePotentials must be numVertPotentials squared");
   edgeList.assign((size_t)2 * numGlobalEdges, 0);
   gf_check(admm_graphfile_read_edges(fname.c_str(), 0, numGlobalEdges, edgeList.data()), "Load");
-  vertPotentials.assign((size_t)numGlobalVerts * k, 0.0f);
-  gf_check(admm_graphfile_read_unaries(fname.c_str(), 0, numGlobalVerts, vertPotentials.data(), 1), "Load");
+  unaryFile.clear();
+  if (part == ROW && numProcs > 1) {
+    unaryFile = fname;  // this strip's share is read at InitOptimization
+    vertPotentials.clear();
+  } else {
+    vertPotentials.assign((size_t)numGlobalVerts * k, 0.0f);
+    gf_check(admm_graphfile_read_unaries(fname.c_str(), 0, numGlobalVerts, vertPotentials.data(), 1), "Load");
+  }
   if (part == EDGE) {
     edgePotentials.assign((size_t)numGlobalEdges * k * k, 0.0f);
     gf_check(admm_graphfile_read_pairwise(fname.c_str(), 0, numGlobalEdges, edgePotentials.data(), 1), "Load");
@@ -150,6 +156,7 @@ void Grid::Generate(unsigned seed, const std::string &pairwise) {
   if (pairwise == "dense") admm_lcg_fill(first_state, (int64_t)k * k, edgePotentials.data());
   sharedTable = true;
   fromFile = false;
+  unaryFile.clear();
   edgeList.clear();
 }
 
@@ -157,10 +164,33 @@ void Grid::SetPotentials(const std::vector<float> &unary, const std::vector<floa
   vertPotentials = unary;
   edgePotentials = pairwise;
   sharedTable = !perEdge;
+  unaryFile.clear();
+}
+
+void Grid::UploadSharesFromFile() {
+  int r0, nr, c0, nc;
+  check(admm_strip_info(ctx, &r0, &nr, &c0, &nc), "admm_strip_info");
+  const int k = numVertPotentials, cols = numGlobalCols, rows = numGlobalRows;
+  const size_t budget = (size_t)64 << 20;  // bytes of host staging
+  std::vector<float> buf;
+  int step = (int)std::max<size_t>(1, budget / (sizeof(float) * k * std::max(cols, 1)));
+  for (int r = r0; r < r0 + nr; r += step) {
+    const int n = std::min(step, r0 + nr - r);
+    buf.resize((size_t)n * cols * k);
+    gf_check(admm_graphfile_read_unaries_block(unaryFile.c_str(), cols, r, n, 0, cols, buf.data(), 1), "Load");
+    check(admm_upload_unaries_rows(ctx, r, n, buf.data()), "admm_upload_unaries_rows");
+  }
+  step = (int)std::max<size_t>(1, budget / (sizeof(float) * k * std::max(nc, 1)));
+  for (int r = 0; r < rows; r += step) {
+    const int n = std::min(step, rows - r);
+    buf.resize((size_t)n * nc * k);
+    gf_check(admm_graphfile_read_unaries_block(unaryFile.c_str(), cols, r, n, c0, nc, buf.data(), 1), "Load");
+    check(admm_upload_unaries_cols(ctx, r, n, buf.data()), "admm_upload_unaries_cols");
+  }
 }
 
 void Grid::InitOptimization() {
-  if (vertPotentials.empty()) throw AdmmError(ADMM_E_STATE, "Generate or SetPotentials before InitOptimization");
+  if (vertPotentials.empty() && unaryFile.empty()) throw AdmmError(ADMM_E_STATE, "Generate or SetPotentials before InitOptimization");
   if (bbox.getBoxRowSize() == 0 && bbox.getBoxColSize() == 0) Partition();
   admm_desc d{};
   d.rows = numGlobalRows; d.cols = numGlobalCols; d.k = numVertPotentials; d.batch = batch;
@@ -178,7 +208,8 @@ void Grid::InitOptimization() {
   if (ctx) { admm_destroy(ctx); ctx = nullptr; }
   const int rc = admm_create(&d, &ctx);
   if (rc != ADMM_OK) throw AdmmError(rc, std::string("admm_create: ") + admm_last_error(nullptr));
-  check(admm_upload_unaries(ctx, vertPotentials.data()), "admm_upload_unaries");
+  if (!unaryFile.empty()) UploadSharesFromFile();
+  else check(admm_upload_unaries(ctx, vertPotentials.data()), "admm_upload_unaries");
   check(admm_upload_pairwise(ctx, edgePotentials.data(), sharedTable ? 0 : 1), "admm_upload_pairwise");
   check(admm_init(ctx), "admm_init");
 }
@@ -205,6 +236,11 @@ std::vector<int> Grid::Labels() {
   std::vector<int> out((size_t)batch * nr * numGlobalCols);
   check(admm_download_labels(ctx, out.data()), "admm_download_labels");
   return out;
+}
+
+void Grid::Trees(TreeSnapshot &out) {
+  if (!ctx) throw AdmmError(ADMM_E_STATE, "InitOptimization before Trees");
+  out.Download(ctx, numVertPotentials);
 }
 
 void Grid::CommunicateGroup(std::vector<Grid *> &strips) {

@@ -11,6 +11,7 @@
 #include "../../../include/admm_hip.h"
 #include "BBox.h"
 #include "GraphBase.h"
+#include "Tree.h"
 
 enum Partitioner { ROW, COL, BLOCK, EDGE };  // Grid.h:21
 
@@ -32,7 +33,13 @@ class Grid : public GraphBase {
   bool sharedTable = true;  // edgePotentials holds one k*k table, not one per edge
   std::vector<int> edgeList;  // 2 * numGlobalEdges vertex ids when the graph came from a file
   bool fromFile = false;
+  // one strip of several, loaded from a grid file: the unaries stay in the file
+  // until InitOptimization reads this strip's rows and columns, a bounded block
+  // at a time, as a rank of the reference reads only its own hyperslab
+  // (Grid.cpp:446-454, 510-523)
+  std::string unaryFile;
   admm_ctx *ctx = nullptr;
+  void UploadSharesFromFile();
 
   void check(int rc, const char *what) const;
 
@@ -82,6 +89,9 @@ class Grid : public GraphBase {
   // chain solver extras (no counterpart in the reference)
   void Objective(double *primal, double *dual);
   std::vector<int> Labels();
+  // The trees' variables under the reference's names (class Edge, Tree.h:20-51):
+  // a snapshot of the device state, waits for the stream.
+  void Trees(TreeSnapshot &out);
 
   int GetRank() const { return rank; }
   int GetNprocs() const { return numProcs; }

@@ -6,7 +6,10 @@
 //
 //   admm <graph file> [--solver edge|chain] [--iters N] [--strips G] [--quiet]
 //   admm <rows> <cols> <k> [--solver edge|chain] [--iters N] [--pairwise potts|trunc_linear|dense]
-//        [--seed S] [--strips G] [--batch B] [--quiet] [--save FILE]
+//        [--seed S] [--strips G] [--batch B] [--quiet] [--save FILE] [--tree N]
+//
+// --tree N prints, after the last iteration, the variables of tree N of strip 0
+// under the names of the reference's class Edge (Tree.h:26-35).
 //
 // --save FILE writes the synthetic problem as a graph file (the reference's
 // GENERATE build, admm.cpp:32-39) before solving it.
@@ -39,7 +42,7 @@ int main(int argc, char *argv[]) {
   const std::string fname = fromFile ? argv[1] : "";
   const int rows = fromFile ? 0 : atoi(argv[1]), cols = fromFile ? 0 : atoi(argv[2]), k = fromFile ? 0 : atoi(argv[3]);
   std::string solver = "edge", pairwise = "potts", saveTo;
-  int totalRuns = 500, strips = 1, batch = 1;  // admm.cpp:74
+  int totalRuns = 500, strips = 1, batch = 1, showTree = -1;  // admm.cpp:74
   unsigned seed = 1234;
   bool quiet = false;
   for (int i = fromFile ? 2 : 4; i < argc; i++) {
@@ -54,6 +57,7 @@ int main(int argc, char *argv[]) {
     else if (!strcmp(argv[i], "--strips")) strips = atoi(val("--strips"));
     else if (!strcmp(argv[i], "--batch")) batch = atoi(val("--batch"));
     else if (!strcmp(argv[i], "--save")) saveTo = val("--save");
+    else if (!strcmp(argv[i], "--tree")) showTree = atoi(val("--tree"));
     else if (!strcmp(argv[i], "--quiet")) quiet = true;
     else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
   }
@@ -102,6 +106,32 @@ int main(int argc, char *argv[]) {
       double primal = 0, dual = 0;
       for (auto &g : grids) { double p, d; g->Objective(&p, &d); primal += p; dual += d; }
       fprintf(stderr, "primal:          %lf\ndual:            %lf\n", primal, dual);
+    }
+    if (showTree >= 0) {
+      TreeSnapshot snap;
+      grids[0]->Trees(snap);
+      auto row = [](const char *name, const float *v, int n) {
+        fprintf(stderr, "%s:", name);
+        for (int i = 0; i < n; i++) fprintf(stderr, " %.9g", v[i]);
+        fprintf(stderr, "\n");
+      };
+      if ((size_t)showTree < snap.edgeVal().size()) {
+        const Edge &e = snap.edgeVal()[(size_t)showTree];
+        row("x_mu_node", e.x_mu_node, NUM_NODE * e.k);
+        row("x_potential_node", e.x_potential_node, NUM_NODE * e.k);
+        row("edge_mu_node", e.edge_mu_node, NUM_NODE * e.k);
+        row("lambda_node", e.lambda_node, NUM_NODE * e.k);
+        row("x_mu_edge", e.x_mu_edge, e.ksquare);
+        row("x_potential_edge", e.x_potential_edge, e.ksquare);
+      } else if ((size_t)showTree < snap.chains().size()) {
+        const Chain &c = snap.chains()[(size_t)showTree];
+        fprintf(stderr, "%s chain %d, x:", c.column ? "column" : "row", c.index);
+        for (int t = 0; t < c.length; t++) fprintf(stderr, " %d", c.x[t * c.stride]);
+        fprintf(stderr, "\n");
+        row("lambda_node[0]", c.lambda_node, c.k);
+      } else {
+        fprintf(stderr, "no tree %d\n", showTree);
+      }
     }
     for (auto &g : grids) g->FinalizeOptimization();
     const double optTime = now() - t;

@@ -162,6 +162,34 @@ int admm_graphfile_read_pairwise(const char *path, int64_t first, int64_t count,
   return read_var(path, "edgePotentials", first, count, out, negate != 0);
 }
 
+int admm_graphfile_read_unaries_block(const char *path, int32_t grid_cols, int32_t row0, int32_t nrows,
+                                      int32_t col0, int32_t ncols, float *out, int negate) {
+  if (!path || (!out && nrows > 0 && ncols > 0)) return fail(ADMM_GF_E_ARG, "null argument");
+  if (grid_cols < 1 || row0 < 0 || nrows < 0 || col0 < 0 || ncols < 0 || (int64_t)col0 + ncols > grid_cols)
+    return fail(ADMM_GF_E_ARG, "bad rectangle");
+  ncfile::Header h;
+  std::string err;
+  admm_graphfile_info info;
+  const int rc = load_info(path, &h, &info);
+  if (rc) return rc;
+  const ncfile::Var *v = h.find_var("verticePotentials");
+  if (!v || v->type != ncfile::NC_FLOAT || !shape_ok(h, info, *v))
+    return fail(ADMM_GF_E_FORMAT, std::string("variable 'verticePotentials' of '") + path + "' does not have the shape the file's sizes state");
+  if (((int64_t)row0 + nrows) * grid_cols > info.num_vertices) return fail(ADMM_GF_E_ARG, "the rectangle reaches past the last vertex");
+  const int64_t w = (int64_t)ncols * info.k;
+  if (ncols == grid_cols) {  // whole rows are contiguous
+    if (!ncfile::read_rows(path, h, "verticePotentials", (int64_t)row0 * grid_cols, (int64_t)nrows * grid_cols, out, &err))
+      return fail(ADMM_GF_E_IO, err);
+  } else {
+    for (int32_t r = 0; r < nrows; r++)
+      if (ncols > 0 && !ncfile::read_rows(path, h, "verticePotentials", (int64_t)(row0 + r) * grid_cols + col0, ncols, out + r * w, &err))
+        return fail(ADMM_GF_E_IO, err);
+  }
+  if (negate)
+    for (int64_t i = 0; i < w * nrows; i++) out[i] = -out[i];  // Grid.cpp:547-560
+  return ADMM_GF_OK;
+}
+
 int admm_graphfile_shared_table(const char *path, float *table, int negate, int *shared) {
   if (!path || !shared) return fail(ADMM_GF_E_ARG, "null argument");
   ncfile::Header h;

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libadmm_graphfile.so")
 # every symbol include/admm_graphfile.h declares
 EXPORTS = [
     "admm_graphfile_read_info", "admm_graphfile_read_edges", "admm_graphfile_read_unaries",
-    "admm_graphfile_read_pairwise", "admm_graphfile_shared_table", "admm_graphfile_write",
+    "admm_graphfile_read_pairwise", "admm_graphfile_read_unaries_block", "admm_graphfile_shared_table", "admm_graphfile_write",
     "admm_graphfile_convert", "admm_graphfile_last_error",
 ]
 
@@ -45,6 +45,7 @@ def _load():
         "admm_graphfile_read_edges": (C.c_int, [cp, C.c_int64, C.c_int64, ip]),
         "admm_graphfile_read_unaries": (C.c_int, [cp, C.c_int64, C.c_int64, fp, C.c_int]),
         "admm_graphfile_read_pairwise": (C.c_int, [cp, C.c_int64, C.c_int64, fp, C.c_int]),
+        "admm_graphfile_read_unaries_block": (C.c_int, [cp] + [C.c_int32] * 5 + [fp, C.c_int]),
         "admm_graphfile_shared_table": (C.c_int, [cp, fp, C.c_int, C.POINTER(C.c_int)]),
         "admm_graphfile_write": (C.c_int, [cp, C.POINTER(GraphFileInfo), ip, fp, fp, C.c_int]),
         "admm_graphfile_convert": (C.c_int, [cp, cp]),
@@ -94,6 +95,15 @@ def read_unaries(path, first=0, count=None, negate=True):
         count = info.num_vertices - first
     out = np.empty((int(count), info.k), dtype=np.float32)
     _ck(lib.admm_graphfile_read_unaries(_path(path), int(first), int(count), out.ctypes.data_as(_fp), 1 if negate else 0))
+    return out
+
+
+def read_unaries_block(path, grid_cols, row0, nrows, col0, ncols, negate=True):
+    """A rectangle of a grid's verticePotentials, [nrows, ncols, k]: what one strip keeps."""
+    info = read_info(path)
+    out = np.empty((int(nrows), int(ncols), info.k), dtype=np.float32)
+    _ck(lib.admm_graphfile_read_unaries_block(_path(path), int(grid_cols), int(row0), int(nrows), int(col0), int(ncols),
+                                              out.ctypes.data_as(_fp), 1 if negate else 0))
     return out
 
 

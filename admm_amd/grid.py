@@ -76,6 +76,7 @@ class Grid:
         self._unary = None
         self._pairwise = None
         self._per_edge = False
+        self._unary_file = None  # strips of a grid file: each strip reads its own share at InitOptimization
         self._h = None
 
     # ---- configuration (Grid.h:98-111) ----
@@ -128,6 +129,7 @@ class Grid:
         pairwise either one k x k table or [E, k*k]."""
         if isinstance(unary, (str, os.PathLike)):
             return self._load_file(unary)
+        self._unary_file = None
         self._unary = np.ascontiguousarray(unary, dtype=np.float32).reshape(-1)
         self._pairwise = np.ascontiguousarray(pairwise, dtype=np.float32).reshape(-1)
         self._per_edge = bool(per_edge)
@@ -139,8 +141,8 @@ class Grid:
         if (info.k, info.rows, info.cols) != (self.k, self.rows, self.cols):
             raise ValueError("SetGlobalInfo disagrees with %s" % (fname,))
         el = graphfile.read_edges(fname).reshape(-1)
-        un = graphfile.read_unaries(fname, negate=True)
         if self.part == EDGE:
+            un = graphfile.read_unaries(fname, negate=True)
             self.SetGraph(info.num_vertices, el)
             self.Load(un, graphfile.read_pairwise(fname, negate=True), per_edge=True)
             return
@@ -152,7 +154,16 @@ class Grid:
         if not shared:
             raise ValueError("the edges of %s carry different pairwise tables; the chain solver needs one shared table" % (fname,))
         self._edge_list = None
-        self.Load(un, table)
+        if self._nprocs > 1:
+            # one strip of several: as a rank of the reference reads only its own
+            # hyperslab (Grid.cpp:446-454, 510-523), this strip's rows and columns
+            # are read, a bounded block at a time, when InitOptimization uploads them
+            self._unary = None
+            self._pairwise = np.ascontiguousarray(table, dtype=np.float32).reshape(-1)
+            self._per_edge = False
+            self._unary_file = os.fspath(fname)
+            return
+        self.Load(graphfile.read_unaries(fname, negate=True), table)
 
     def Save(self, fname, version=0):
         """Grid::Save (Grid.cpp:1049-1131): the potentials this object holds,
@@ -198,9 +209,39 @@ class Grid:
         self.Load(np.concatenate(parts), pairwise_table(pairwise, self.k, st))
 
     # ---- optimisation (admm.cpp:73-101) ----
+    UPLOAD_BLOCK_BYTES = 64 << 20  # host staging of a strip that reads its share from a file
+
+    def _upload_shares_from_file(self):
+        """This strip's rows, then its columns of every row, block by block."""
+        _, nrows, c0, ncols = self.StripInfo()
+        r0 = self.StripInfo()[0]
+        k, cols = self.k, self.cols
+        step = max(1, self.UPLOAD_BLOCK_BYTES // (4 * k * max(cols, 1)))
+        for r in range(r0, r0 + nrows, step):
+            n = min(step, r0 + nrows - r)
+            blk = graphfile.read_unaries_block(self._unary_file, cols, r, n, 0, cols, negate=True)
+            self._ck(lib.admm_upload_unaries_rows(self._h, r, n, _f(blk)))
+        step = max(1, self.UPLOAD_BLOCK_BYTES // (4 * k * max(ncols, 1)))
+        for r in range(0, self.rows, step):
+            n = min(step, self.rows - r)
+            blk = graphfile.read_unaries_block(self._unary_file, cols, r, n, c0, ncols, negate=True)
+            self._ck(lib.admm_upload_unaries_cols(self._h, r, n, _f(blk)))
+
     def InitOptimization(self):
-        if self._unary is None:
+        if self._unary is None and self._unary_file is None:
             raise AdmmError(-2, "Load or Generate before InitOptimization")
+        # sizes the C side will read: a mismatch would run past the numpy buffers
+        graph = self._edge_list is not None
+        if self.k < 1 or (not graph and (self.rows < 1 or self.cols < 1)):
+            raise ValueError("SetGlobalInfo before InitOptimization")
+        nv = self._num_vertices if graph else self.batch * self.rows * self.cols
+        ne = self._edge_list.size // 2 if graph else self.rows * (self.cols - 1) + self.cols * (self.rows - 1)
+        if self._unary is not None and self._unary.size != nv * self.k:
+            raise ValueError("unary potentials hold %d values, %d vertices x %d labels expected" % (self._unary.size, nv, self.k))
+        want_pw = ne * self.k * self.k if self._per_edge else self.k * self.k
+        if self._pairwise is None or self._pairwise.size != want_pw:
+            raise ValueError("pairwise potentials hold %d values, %d expected" % (0 if self._pairwise is None else self._pairwise.size, want_pw))
+        self.close()  # a second InitOptimization replaces the context
         d = AdmmDesc()
         d.rows, d.cols, d.k, d.batch = self.rows, self.cols, self.k, self.batch
         d.solver = SOLVER_EDGE_BETHE if self.part == EDGE else SOLVER_CHAIN_MINSUM
@@ -216,7 +257,10 @@ class Grid:
         if rc != 0:
             raise AdmmError(rc, (lib.admm_last_error(None) or b"").decode())
         self._h = h
-        self._ck(lib.admm_upload_unaries(self._h, _f(self._unary)))
+        if self._unary is None:
+            self._upload_shares_from_file()
+        else:
+            self._ck(lib.admm_upload_unaries(self._h, _f(self._unary)))
         self._ck(lib.admm_upload_pairwise(self._h, _f(self._pairwise), 1 if self._per_edge else 0))
         self._ck(lib.admm_init(self._h))
 
@@ -350,6 +394,12 @@ class Grid:
         kp, ns, potts = C.c_int(), C.c_int(), C.c_int()
         self._ck(lib.admm_sweep_kernel_info(self._h, C.byref(kp), C.byref(ns), C.byref(potts)))
         return kp.value, ns.value, bool(potts.value)
+
+    def SweepKernelName(self):
+        """The sweep kernel's instance as a kernel trace names it."""
+        buf = C.create_string_buffer(160)
+        self._ck(lib.admm_sweep_kernel_name(self._h, buf, 160))
+        return buf.value.decode()
 
     def close(self):
         if self._h:

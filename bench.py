@@ -35,62 +35,160 @@ WORKLOADS = {
     "1024x1024_k64_dense": (1024, 1024, 64, 1, "dense"),
     "256x(256x256)_k8_potts": (256, 256, 8, 256, "potts"),
     "64x64_k4_potts": (64, 64, 4, 1, "potts"),
+    # the reference's own algorithm (one tree per edge, Tree.cpp:112-274): secondary
+    "edge_64x64_k4_potts": (64, 64, 4, 1, "potts"),
+    "edge_512x512_k16_trunc_linear": (512, 512, 16, 1, "trunc_linear"),
+    "edge_512x512_k32_potts": (512, 512, 32, 1, "potts"),
 }
 
 
 def bytes_per_iteration(V, k):
-    """Algorithmic HBM bytes of one ADMM iteration: V * (36 k + 24)."""
+    """Algorithmic HBM bytes of one ADMM iteration of the chain solver, float32 operands
+    and int32 labels: V * (36 k + 24)."""
     return V * (36 * k + 24)
 
 
 def sweep_bytes(V, k):
-    """Share of the chain sweep kernel: theta read twice (8k), both lambda
-    arrays read and written (16k), consensus read twice (8k), both label arrays
-    read and written (16)."""
+    """Share of the chain sweep kernel in that figure: theta read twice (8k), both lambda
+    arrays read and written (16k), consensus read twice (8k), both label arrays read and
+    written (16)."""
     return V * (32 * k + 16)
 
 
-def cpu_baseline(rows, cols, k, pairwise, seed, seconds_budget=25.0):
-    """The CPU restatement of the same iteration, timed on the host cores."""
+def stored_bytes(V, k, kp, chains_per_wave, potts, lam16, lam_shared):
+    """Bytes one sweep launch has to move given how the operands are stored: a lower bound
+    for this representation (every array touched once per use, nothing re-read).
+      theta       4k per node, read by the row chains and by the column chains
+      multipliers one array on one device (read by both sets, written once) or one per set
+                  (each read and written); 2 bytes per entry as int16 counts, else 4
+      labels      1 byte: every set reads its own and the crossing chains', writes its own
+      back-pointers  Potts step: two 64-bit lane masks per wavefront step (16 B for
+                  chains_per_wave nodes), written by the forward pass and read by the
+                  trace-back; general step: one byte per padded label per node, likewise"""
+    lam_el = 2 if lam16 else 4
+    lam = lam_el * k * (3 if lam_shared else 4)
+    labels = 2 * 3
+    bp = 2 * 2 * (16.0 / chains_per_wave if potts else kp)
+    return V * (8 * k + lam + labels + bp)
+
+
+def edge_bytes(V, E, k):
+    """Algorithmic bytes of one iteration of the edge solver: per edge mu_e read + written and
+    theta_e read (3 k^2), the six 2k node vectors of class Edge read or written once or twice
+    (14 k), plus the consensus row of every vertex."""
+    return 4 * (E * (3 * k * k + 14 * k) + V * k)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(rows, cols, k, pairwise, seed, batch=1):
+    """The same iteration on the host cores, as bounded samples (about 20 s in all):
+    the CPU restatement of the chain solver with one chain per thread (the headline
+    `value`) and on one thread, and the reference's own Tree.cpp (built into oracle/_ref
+    where its sources were present) on a small grid of the same k, since the reference has
+    only the per-edge solver."""
     from oracle import oracle as O
-    threads = min(16, os.cpu_count() or 1)
-    O.set_threads(threads)
+    ncpu = os.cpu_count() or 1
+    threads = min(16, ncpu)
+    V1 = rows * cols
     un, W = O.synth_problem(rows, cols, k, seed, pairwise)
+    out = {"unit": "it/s", "kind": "port", "nproc": ncpu, "cpu_model": cpu_model()}
+
+    # all threads: whole iterations of one grid (a batch is `batch` such grids in a row)
+    O.set_threads(threads)
     o = O.ChainOracle(rows, cols, k, un, W)
     o.init()
     t0 = time.perf_counter()
     its = 0
     while True:
-        o.compute()
-        o.update()
-        o.objective(dual=False)
+        o.compute(); o.update(); o.objective(dual=False)
         its += 1
-        if time.perf_counter() - t0 > seconds_budget * 0.5 or its >= 20:
+        if time.perf_counter() - t0 > 8.0 or its >= 20:
             break
     dt = time.perf_counter() - t0
-    return {
-        "value": its / dt, "unit": "it/s", "cores": threads, "kind": "port",
-        "sample": "%d full ADMM iterations (compute + update + linear objective) of the %dx%d k=%d grid, "
-                  "oracle/admm_oracle.c with one chain per OpenMP thread" % (its, rows, cols, k),
-    }
+    out["value"] = its / dt / batch
+    out["cores"] = threads
+    out["sample"] = ("%d full ADMM iterations (compute + update + linear objective) of one %dx%d k=%d grid%s, "
+                     "oracle/admm_oracle.c with one chain per OpenMP thread"
+                     % (its, rows, cols, k, ", divided by the %d grids of the batch" % batch if batch > 1 else ""))
+
+    # one thread: a slice of the chains of one iteration, scaled to all of them
+    O.set_threads(1)
+    nr = max(1, min(rows, int(rows * 4.0 / max(1.0, dt / its * threads))))  # about 4 s
+    nc = max(1, min(cols, int(cols * nr / rows)))
+    t0 = time.perf_counter()
+    o.compute(0, nr, 0, nc)
+    d1 = time.perf_counter() - t0
+    frac = (nr * cols + nc * rows) / (2.0 * V1)
+    out["single_thread"] = {
+        "value": frac / d1 / batch, "unit": "it/s", "cores": 1,
+        "sample": "Compute of %d of %d row chains and %d of %d column chains, scaled to all chains" % (nr, rows, nc, cols)}
+    del o
+
+    # the reference's own solver (per-edge Bethe sum-product) at this k, one core
+    ref = O.load_ref()
+    R2 = C2 = 64 if k <= 16 else 32
+    un2, W2 = O.synth_problem(R2, C2, k, seed, pairwise)
+    el = O.grid_edges(R2, C2)
+    E2 = el.size // 2
+    ep = np.tile(W2.reshape(-1), E2)
+    e = O.RefEdge(ref, R2 * C2, el, k, un2, ep) if ref is not None else O.EdgeOracle(R2 * C2, el, k, un2, ep)
+    e.init()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        e.compute(); e.update(); e.objective()
+        n += 1
+        if time.perf_counter() - t0 > 4.0 or n >= 50:
+            break
+    de = (time.perf_counter() - t0) / n
+    E1 = rows * (cols - 1) + cols * (rows - 1)
+    out["edge_solver"] = {
+        "kind": "reference" if ref is not None else "port", "cores": 1,
+        "us_per_edge_iteration": 1e6 * de / E2,
+        "value": 1.0 / (de / E2 * E1) / batch, "unit": "it/s",
+        "sample": "%d iterations of a %dx%d k=%d grid (%d edges) through %s, scaled by edges to the %dx%d grid"
+                  % (n, R2, C2, k, E2, "the reference's Tree.cpp (oracle/_ref)" if ref is not None else "oracle/admm_oracle.c", rows, cols)}
+    return out
 
 
-def measured_traffic(workload, world):
-    """HBM bytes per sweep launch from the committed counter passes (FETCH_SIZE
-    and WRITE_SIZE cannot be collected from inside this process), or None when
-    no pass covers this workload."""
+def measured_traffic(workload, world, kernel):
+    """HBM bytes per launch of the dominant kernel from the committed counter passes
+    (FETCH_SIZE and WRITE_SIZE come from rocprofv3 --pmc runs of this same command; they
+    cannot be collected from inside this process).  Only a pass of the same workload and
+    the same kernel instance counts; otherwise None."""
     import glob
     if world != 1:
         return None, None
     here = os.path.dirname(os.path.abspath(__file__))
-    for f in sorted(glob.glob(os.path.join(here, "profiles", "r*_hbm_traffic_sweep.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(here, "profiles", "r*_hbm_traffic_*.json")), reverse=True):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if str(d.get("workload", "")).startswith(workload):
+        if str(d.get("workload", "")).startswith(workload) and kernel in str(d.get("kernel", "")):
             return d.get("hbm_bytes_per_launch"), "profiles/" + os.path.basename(f)
     return None, None
+
+
+def make_grid(args, rank, nprocs, device, rows, cols, k, batch, pairwise, seed, edge):
+    g = A.Grid(rank=rank, nprocs=nprocs, device=device)
+    g.SetPartitioner(A.EDGE if edge else A.ROW)
+    g.SetPenalties(0.5, 1.0)  # admm.cpp:44
+    g.SetGlobalInfo(rows, cols, k, batch=batch)
+    g.exchange = 0 if args.exchange == "labels" else 1
+    g.Generate(seed=seed, pairwise=pairwise)
+    g.InitOptimization()
+    g._unary = None  # the host copy is no longer needed
+    return g
 
 
 def main():
@@ -123,6 +221,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    edge = args.workload.startswith("edge_")
     rows, cols, k, batch, pairwise = WORKLOADS[args.workload]
     my_batch = batch
     nprocs_for_grid = world
@@ -136,14 +235,9 @@ def main():
     ndev = A._lib.lib.admm_device_count()
     if ndev < 1:
         sys.exit("bench.py needs a HIP device (there is no CPU fallback)")
-    g = A.Grid(rank=rank if nprocs_for_grid > 1 else 0, nprocs=nprocs_for_grid, device=local_rank % ndev)
-    g.SetPartitioner(A.ROW)
-    g.SetPenalties(0.5, 1.0)  # admm.cpp:44
-    g.SetGlobalInfo(rows, cols, k, batch=my_batch)
-    g.exchange = 0 if args.exchange == "labels" else 1
-    g.Generate(seed=args.seed + b0, pairwise=pairwise)
-    g.InitOptimization()
-    g._unary = None  # the host copy is no longer needed
+    device = local_rank % ndev
+    grank = rank if nprocs_for_grid > 1 else 0
+    g = make_grid(args, grank, nprocs_for_grid, device, rows, cols, k, my_batch, pairwise, args.seed + b0, edge)
     transport = "none"
     if nprocs_for_grid > 1:
         transport = args.transport
@@ -177,20 +271,15 @@ def main():
             else:
                 transport = "host"
                 g.close()
-                g = A.Grid(rank=rank, nprocs=nprocs_for_grid, device=local_rank % ndev)
-                g.SetPartitioner(A.ROW)
-                g.SetPenalties(0.5, 1.0)
-                g.SetGlobalInfo(rows, cols, k, batch=my_batch)
-                g.exchange = 0 if args.exchange == "labels" else 1
-                g.Generate(seed=args.seed + b0, pairwise=pairwise)
-                g.InitOptimization()
-                g._unary = None
+                g = make_grid(args, grank, nprocs_for_grid, device, rows, cols, k, my_batch, pairwise, args.seed + b0, edge)
 
     def barrier():
         g.Synchronize()
         if dist is not None:
             dist.barrier()
         g.Synchronize()
+
+    edge_obj = []
 
     def step(i):
         g.Compute()
@@ -199,7 +288,10 @@ def main():
         else:
             g.Communicate()
         g.Update()
-        g.ObjectiveEnqueue(1 + i)
+        if edge:
+            edge_obj.append(g.ComputeLinearObj())  # the reference's loop reads it every iteration (admm.cpp:94)
+        else:
+            g.ObjectiveEnqueue(1 + i)
 
     for i in range(args.warmup):
         step(i)
@@ -217,28 +309,81 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
 
-    sweep_ms, launches = g.ProfileRead()
+    kernel_ms, launches = g.ProfileRead()
     g.ProfileReset(False)
-    linear = g.ObjectiveRead(1 + args.warmup, args.steps)
-    primal, dual = g.Objective(dual=True)  # decoded energy and dual bound, evaluated once at the end
-    last = np.array([primal, linear[-1], dual], dtype=np.float64)
+    if edge:
+        last = np.array([edge_obj[-1], edge_obj[-1], float("nan")], dtype=np.float64)
+    else:
+        linear = g.ObjectiveRead(1 + args.warmup, args.steps)
+        primal, dual = g.Objective(dual=True)  # decoded energy and dual bound, evaluated once at the end
+        last = np.array([primal, linear[-1], dual], dtype=np.float64)
     if dist is not None:
         import torch
         tt = torch.from_numpy(last)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)  # admm.cpp:95
-        sm = torch.tensor([sweep_ms], dtype=torch.float64)
+        sm = torch.tensor([kernel_ms], dtype=torch.float64)
         dist.all_reduce(sm, op=dist.ReduceOp.MAX)
-        sweep_ms = float(sm[0])
+        kernel_ms = float(sm[0])
 
     V = rows * cols * batch
+    E = (rows * (cols - 1) + cols * (rows - 1)) * batch
     it_per_s = args.steps / elapsed
-    b_it = bytes_per_iteration(V, k)
-    sweep_b = sweep_bytes(V, k) / world
-    achieved = sweep_b / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+    sec = kernel_ms * 1e-3
 
     out = None
     if rank == 0:
-        traffic, traffic_src = measured_traffic(args.workload, world)
+        config = {
+            "workload": args.workload, "rows": rows, "cols": cols, "k": k, "batch": batch,
+            "pairwise": pairwise, "solver": "edge_bethe" if edge else "chain_minsum", "penalty": 0.5, "rho": 1.0,
+            "partition": ("edge slices x%d" % world) if edge else ("row/column strips x%d" % world if batch == 1 else "batch sharded x%d" % world),
+            "exchange": args.exchange, "transport": transport,
+        }
+        if edge:
+            b_it = edge_bytes(V, E, k)
+            kernel = "edge_solve_kernel<%d>" % (1 << max(1, (k - 1).bit_length()))
+            config["kernel"] = kernel
+            traffic, traffic_src = measured_traffic(args.workload, world, "edge_solve_kernel")
+            # what the kernel is really bound by: binary64 exp / log on the vector ALU
+            transc = E * (4 * k * k + 4 * k)
+            roof = {
+                "kernel": kernel, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "achieved": b_it / world / sec / 1e9 if sec > 0 else 0.0,
+                "bytes_per_launch": b_it / world, "ms_per_launch": kernel_ms, "launches_timed": launches,
+                "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                "transcendentals_per_launch": transc, "transcendentals_per_sec": transc / world / sec if sec > 0 else 0.0,
+                "note": "achieved = algorithmic bytes 4*(E*(3k^2+14k)+V*k) over the kernel's duration.  The kernel is not "
+                        "HBM bound: every edge costs 4k^2+4k binary64 exp/log calls (the reference's arithmetic, kept for "
+                        "parity), and transcendentals_per_sec is the rate that limits it.",
+            }
+            roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+        else:
+            kp, ns, potts = g.SweepKernelInfo()
+            kernel = g.SweepKernelName()
+            lam16 = kernel.endswith("true>")
+            config.update({"kernel": kernel, "potts_step": potts, "lam16": lam16})
+            b_it = bytes_per_iteration(V, k)
+            algo = sweep_bytes(V, k) / world
+            model = stored_bytes(V, k, kp, 64 // (kp * ns), potts, lam16, lam_shared=(nprocs_for_grid == 1)) / world
+            traffic, traffic_src = measured_traffic(args.workload, world, kernel)
+            moved = traffic if traffic else model
+            roof = {
+                "kernel": kernel, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                # the rate the memory system ran at: bytes really moved over the kernel's duration
+                "achieved": moved / sec / 1e9 if sec > 0 else 0.0,
+                "achieved_from": "traffic" if traffic else "stored_bytes_model",
+                "ms_per_launch": kernel_ms, "launches_timed": launches,
+                "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                "stored_bytes_model": model, "frac_of_model": model / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else 0.0,
+                "algorithmic_bytes": algo, "algorithmic_gbps": algo / sec / 1e9 if sec > 0 else 0.0,
+                "note": "frac = bytes the kernel moves per launch (HBM counters of a rocprofv3 pass of this command when one is "
+                        "committed for this kernel instance, else the stored-representation model) / kernel time / 8 TB/s.  "
+                        "stored_bytes_model is the least this representation can move: theta twice, the multipliers (one "
+                        "int16 array read twice and written once on one device with a Potts table and a power-of-two "
+                        "penalty), byte labels, back-pointer masks.  algorithmic_bytes = V*(32k+16) prices the same launch "
+                        "with float32 multipliers, a consensus array and int32 labels; the kernel moves fewer bytes than "
+                        "that (same numbers, exact), so algorithmic_gbps may exceed the peak and is not a rate.",
+            }
+            roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
         out = {
             "metric": "admm_iterations_per_sec",
             "value": it_per_s,
@@ -252,34 +397,15 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {
-                "workload": args.workload, "rows": rows, "cols": cols, "k": k, "batch": batch,
-                "pairwise": pairwise, "solver": "chain_minsum", "penalty": 0.5, "rho": 1.0,
-                "partition": "row/column strips x%d" % world if batch == 1 else "batch sharded x%d" % world,
-                "exchange": args.exchange, "transport": transport,
-            },
-            "label_updates_per_sec": 2.0 * V * it_per_s,
+            "config": config,
+            "label_updates_per_sec": None if edge else 2.0 * V * it_per_s,
             "iteration_bytes": b_it,
             "iteration_gbps": b_it * it_per_s / 1e9,
-            "iteration_frac_of_hbm_peak": b_it * it_per_s / 1e9 / (HBM_PEAK_GBS * world),
             "final_objective": {"primal": float(last[0]), "linear": float(last[1]), "dual": float(last[2])},
-            "roofline": {
-                "kernel": "chain_sweep_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "bytes_per_launch": sweep_b, "ms_per_launch": sweep_ms, "launches_timed": launches,
-                "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                # the rate the memory system really ran at: measured bytes over the same duration
-                "traffic_gbps": (traffic / (sweep_ms * 1e-3) / 1e9) if (traffic and sweep_ms > 0) else None,
-                "traffic_frac": (traffic / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and sweep_ms > 0) else None,
-                "note": "achieved prices the launch with the algorithmic bytes V*(32k+16) (float32 operands, int32 labels); "
-                        "the kernel moves fewer: the consensus is rebuilt from two labels instead of read, labels are bytes, "
-                        "and on one device with a Potts table and a power-of-two penalty the multipliers are one int16 array "
-                        "of exact counts.  frac above 1 therefore means bytes saved, not a rate above the HBM peak; "
-                        "traffic_gbps is the measured rate.",
-            },
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(rows, cols, k, pairwise, args.seed)
+            out["cpu_baseline"] = cpu_baseline(rows, cols, k, pairwise, args.seed, batch)
     g.FinalizeOptimization()
     g.close()
     if dist is not None:
@@ -287,6 +413,7 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":

@@ -63,6 +63,14 @@ int admm_graphfile_read_edges(const char *path, int64_t first, int64_t count, in
 int admm_graphfile_read_unaries(const char *path, int64_t first, int64_t count, float *out, int negate);
 int admm_graphfile_read_pairwise(const char *path, int64_t first, int64_t count, float *out, int negate);
 
+/* A rectangle of a grid's verticePotentials: for each of the `nrows` grid rows
+ * from `row0` on, the `ncols` vertices from column `col0` on, out =
+ * [nrows][ncols][k], where vertex (r, c) is row r * grid_cols + c of the
+ * variable.  What one rank of a row / column strip partition keeps
+ * (Grid::PartitionByRow reads its rows the same way, Grid.cpp:886-903). */
+int admm_graphfile_read_unaries_block(const char *path, int32_t grid_cols, int32_t row0, int32_t nrows,
+                                      int32_t col0, int32_t ncols, float *out, int negate);
+
 /* Whether every edge of the file carries the same k2-entry table (what the
  * chain solver needs).  table (k2 floats, may be NULL) receives the table of
  * edge 0, sign-flipped when negate != 0; *shared is 1 or 0.  Streams the

@@ -88,6 +88,18 @@ const char *admm_last_error(const admm_ctx *ctx);
  * values Grid holds after the loader's sign flip (Grid.cpp:510-523, 547-553).
  * Always the whole problem; a strip context keeps its own share. */
 int admm_upload_unaries(admm_ctx *ctx, const float *unary);
+/* The same, a share at a time, for a caller that stages only what this strip
+ * keeps: in the reference every rank reads its own hyperslab of the file and
+ * nothing else (Grid.cpp:446-454, 510-523).  Chain solver, batch == 1.
+ * _rows: whole grid rows [nrows][cols][k], global rows row0 .. row0+nrows-1,
+ * inside this context's row strip (admm_strip_info).  _cols: this context's
+ * column strip of global rows row0 .. row0+nrows-1, [nrows][strip cols][k]; any
+ * rows of the grid.  With one strip the rows are the whole problem and _cols
+ * copies nothing.  admm_init needs every row of both shares; the first share
+ * after an admm_init starts a new upload (everything has to arrive again).
+ * Each call returns when the caller's buffer may be reused. */
+int admm_upload_unaries_rows(admm_ctx *ctx, int row0, int nrows, const float *rows);
+int admm_upload_unaries_cols(admm_ctx *ctx, int row0, int nrows, const float *cols);
 /* Pairwise costs after the sign flip (Grid.cpp:529-543, 554-560).
  * per_edge = 1: [num_edges][k*k] in edge-list order (edge solver);
  * per_edge = 0: one k*k table W[a*k+b], a = label of the edge's first vertex,
@@ -222,6 +234,12 @@ int admm_profile_read(admm_ctx *ctx, double *compute_ms_avg, int *launches);
  * diagonal, one non-negative value everywhere else) is the one chosen.  A
  * diagnostic without a counterpart in the reference. */
 int admm_sweep_kernel_info(admm_ctx *ctx, int *label_lanes, int *lanes_per_label, int *potts);
+/* The same as the name a kernel trace shows for it, e.g.
+ * "chain_sweep_kernel<32, 1, 8, 4, false, true, true>" (labels padded to, lanes
+ * per label, prefetch groups, wavefronts per SIMD, dual evaluation, Potts step,
+ * int16 multiplier counts), so that a measurement can say which instance it
+ * timed.  buf receives at most len bytes, NUL-terminated. */
+int admm_sweep_kernel_name(admm_ctx *ctx, char *buf, int len);
 
 /* Number of HIP devices visible to this process (0 when there is none). */
 int admm_device_count(void);

@@ -593,6 +593,9 @@ static inline float chain_mu(int x, int l, float inv_k) {
   return x < 0 ? inv_k : (x == l ? 1.0f : 0.0f);
 }
 
+static int g_threads = 1;
+static int g_threads_fwd(void) { return g_threads; }
+
 /* min over src of (M[src] + W[...]) with the lowest src attaining it.
  * transposed = 0: W[src][tgt] (left half); 1: W[tgt][src] (right half, join). */
 static inline float minplus(const float *M, const float *W, int k, int tgt, int transposed, int *arg) {
@@ -667,6 +670,25 @@ static float chain_minsum(const float *th, const float *W, int k, int T, float *
   return value;
 }
 
+/* The subproblem alone, for tests that check it against an independent
+ * solver: n chains of T nodes with adjusted unaries th[n][T][k] and the table
+ * W[a][b]; x[n][T] receives the labels, val[n] the chain minima. */
+void oracle_chain_minsum_batch(const float *th, const float *W, int k, int T, int n, int *x, float *val) {
+#ifdef _OPENMP
+#pragma omp parallel num_threads(g_threads_fwd())
+#endif
+  {
+    float *M = falloc(3LL * k);
+    unsigned char *bp = (unsigned char *)malloc((size_t)T * k + 1);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
+#endif
+    for (int c = 0; c < n; c++)
+      val[c] = chain_minsum(th + (size_t)c * T * k, W, k, T, M, bp, x + (size_t)c * T, 1);
+    free(M); free(bp);
+  }
+}
+
 /* One chain of T nodes; node t is first + t*step. */
 static void chain_solve(oracle_chain *o, float *lam, int *x, long long first,
                         long long step, int T, float *th, float *M, unsigned char *bp) {
@@ -685,7 +707,6 @@ static void chain_solve(oracle_chain *o, float *lam, int *x, long long first,
   chain_minsum(th, o->Wt, k, T, M, bp, x + first, step);
 }
 
-static int g_threads = 1;
 void oracle_set_threads(int n) { g_threads = n > 0 ? n : 1; }
 
 /* Chains are independent inside one Compute, so the baseline may run one chain

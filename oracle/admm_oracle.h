@@ -117,6 +117,10 @@ void oracle_chain_update(oracle_chain *o);
 void oracle_chain_objective(const oracle_chain *o, double *primal, double *dual,
                             double *linear);
 void oracle_chain_labels(const oracle_chain *o, int *labels);  /* R*C decoded */
+/* The chain subproblem alone (two-ended min-sum, lowest index on ties): n
+ * chains of T nodes, adjusted unaries th[n][T][k], table W[a][b]; labels to
+ * x[n][T], chain minima to val[n]. */
+void oracle_chain_minsum_batch(const float *th, const float *W, int k, int T, int n, int *x, float *val);
 int *oracle_chain_xrow(oracle_chain *o);       /* R*C, -1 before first solve */
 int *oracle_chain_xcol(oracle_chain *o);       /* R*C */
 float *oracle_chain_consensus(oracle_chain *o);   /* R*C*k */

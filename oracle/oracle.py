@@ -81,6 +81,8 @@ def _load():
         f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.oracle_chain_objective.restype = None
     lib.oracle_chain_objective.argtypes = [C.c_void_p, _dp, _dp, _dp]
+    lib.oracle_chain_minsum_batch.restype = None
+    lib.oracle_chain_minsum_batch.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, _ip, _fp]
     lib.oracle_chain_labels.restype = None
     lib.oracle_chain_labels.argtypes = [C.c_void_p, _ip]
     for n in ("xrow", "xcol"):
@@ -320,6 +322,19 @@ class ChainOracle:
     lambda_row = property(lambda s: s._fview("lambda_row"))
     lambda_col = property(lambda s: s._fview("lambda_col"))
     theta = property(lambda s: s._fview("theta"))
+
+
+def chain_minsum_batch(th, W):
+    """The chain subproblem alone: th [n, T, k] adjusted unaries, W [k, k].  Returns
+    (labels [n, T] int32, chain minima [n] float32) of the two-ended sweep."""
+    th = np.ascontiguousarray(th, dtype=np.float32)
+    n, T, k = th.shape
+    w = np.ascontiguousarray(W, dtype=np.float32).reshape(-1)
+    assert w.size == k * k
+    x = np.empty((n, T), dtype=np.int32)
+    val = np.empty(n, dtype=np.float32)
+    lib.oracle_chain_minsum_batch(_f(th), _f(w), k, T, n, _i(x), _f(val))
+    return x, val
 
 
 # ---------------------------------------------------------------- reference Tree.cpp

@@ -108,6 +108,11 @@ def test_cpp_driver_reads_the_file_it_saved(tmp_path):
         b = subprocess.run([ADMM, str(f), "--solver", solver, "--iters", "10"], capture_output=True, text=True, timeout=300)
         assert b.returncode == 0, b.stderr[-2000:]
         assert pick(a.stderr) == pick(b.stderr) and len(pick(a.stderr)) >= 10
+        if solver == "chain":
+            # three strips, each reading only its own rows and columns of the file
+            c3 = subprocess.run([ADMM, str(f), "--solver", solver, "--iters", "10", "--strips", "3"], capture_output=True, text=True, timeout=300)
+            assert c3.returncode == 0, c3.stderr[-2000:]
+            assert pick(c3.stderr) == pick(a.stderr)
     # a file that does not exist is an error message and a non-zero status
     c = subprocess.run([ADMM, str(tmp_path / "none.nc")], capture_output=True, text=True, timeout=60)
     assert c.returncode != 0 and "cannot open" in c.stderr

@@ -42,3 +42,22 @@ def test_driver_chain_strips_agree():
     pick = lambda s: re.findall(r"(totalObj|primal|dual):\s+([-0-9.]+)", s)
     assert pick(a) == pick(b)
     assert len(pick(a)) == 22
+
+
+def test_driver_shows_a_tree_under_the_reference_member_names():
+    """3 x 3, k = 2, three iterations: edge 0's marginals and multipliers as the unmodified
+    reference printed them (class Edge members, Tree.h:26-35), through the host Edge view."""
+    known = json.load(open(os.path.join(ROOT, "tests", "golden", "known_answers.json")))["3x3_k2"]
+    err = _run(3, 3, 2, "--solver", "edge", "--iters", 3, "--tree", 0)
+    row = lambda name: [float(x) for x in re.search(r"^%s:((?: [-0-9.eE+]+)+)$" % name, err, flags=re.M).group(1).split()]
+    np = __import__("numpy")
+    np.testing.assert_allclose(row("x_mu_node"), known["it3_edge0_mu"], rtol=1e-5)
+    np.testing.assert_allclose(row("lambda_node"), known["it3_edge0_lambda"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(row("x_potential_node"), known["edge0_x_potential_node"], rtol=1e-7)
+    assert len(row("x_mu_edge")) == 4 and len(row("edge_mu_node")) == 4
+
+
+def test_driver_shows_a_chain():
+    err = _run(6, 9, 4, "--solver", "chain", "--iters", 2, "--tree", 7, "--quiet")  # 6 row chains, then column 1
+    m = re.search(r"^column chain 1, x:((?: \d+)+)$", err, flags=re.M)
+    assert m and len(m.group(1).split()) == 6

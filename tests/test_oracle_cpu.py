@@ -167,9 +167,6 @@ def test_chain_oracle_against_brute_force():
         th = (un[0] / np.float32(2)).astype(np.float32)
         best = None
         for lab in itertools.product(range(k), repeat=T):
-            e = np.float32(th[0, lab[0]])
-            for t in range(1, T):
-                e = np.float32(e) + np.float32(0)  # keep float32
             val = sum(float(th[t, lab[t]]) for t in range(T)) + sum(float(W[lab[t], lab[t + 1]]) for t in range(T - 1))
             if best is None or val < best[0] - 1e-9:
                 best = (val, lab)

@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Turns the raw output of tools/profile_round.sh (gpurun_out/<tag>/) into the
-small files kept under profiles/: bench lines, the kernel statistics of the
-default bench command, and the HBM traffic of the sweep kernel per launch.
+small files kept under profiles/: per workload the bench line, the kernel
+statistics of the same command, and the HBM traffic of its dominant kernel per
+launch.
 
-    python tools/distill_profiles.py r01
+    python tools/distill_profiles.py r02
 
 HBM bytes: FETCH_SIZE and WRITE_SIZE are reported in KiB.  On gfx950
 FETCH_SIZE counts 64 B for each 128-B read request, so reads are doubled; the
-factor is checked in the same pass on kernels whose read volume is known
+factor is checked in the same pass on a kernel whose read volume is known
 (chain_init_theta_kernel reads its array exactly once).  WRITE_SIZE needs no
 correction.
 """
@@ -19,12 +20,11 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SWEEP = "chain_sweep_kernel<32, 1, 8, 4, false, true, true>"
-WORKLOAD = "2048x2048_k32_potts"
+sys.path.insert(0, ROOT)
 
 
-def counter(tag, sub, name):
-    files = glob.glob(os.path.join(ROOT, "gpurun_out", tag, sub, "**", "*counter_collection.csv"), recursive=True)
+def counter(src, sub, name):
+    files = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)
     per = {}
     for f in files:
         for r in csv.DictReader(open(f)):
@@ -35,43 +35,58 @@ def counter(tag, sub, name):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    for f in glob.glob(os.path.join(src, "bench_*.json")):
-        name = os.path.basename(f).replace("(", "").replace(")", "")
+    for f in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
+        n = os.path.basename(f)[len("bench_"):-len(".json")]
         line = [l for l in open(f).read().splitlines() if l.startswith("{")]
-        if line:
-            json.loads(line[-1])
-            open(os.path.join(dst, "%s_%s" % (tag, name)), "w").write(line[-1] + "\n")
-    stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
-    if stats:
-        shutil.copy(stats[0], os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, WORKLOAD)))
-    fetch, write = counter(tag, "pmc_fetch", "FETCH_SIZE"), counter(tag, "pmc_write", "WRITE_SIZE")
-    fk = [k for k in fetch if SWEEP in k]
-    wk = [k for k in write if SWEEP in k]
-    if fk and wk:
-        rd = fetch[fk[0]] * 1024.0 * 2.0
-        wr = write[wk[0]] * 1024.0
-        V, k = 2048 * 2048, 32
+        if not line:
+            continue
+        bench = json.loads(line[-1])
+        open(os.path.join(dst, "%s_bench_%s.json" % (tag, n)), "w").write(line[-1] + "\n")
+        stats = glob.glob(os.path.join(src, "trace_" + n, "**", "*kernel_stats.csv"), recursive=True)
+        dominant = None
+        if stats:
+            shutil.copy(stats[0], os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, n)))
+            rows = list(csv.DictReader(open(stats[0])))
+            rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+            dominant = rows[0]
+        fetch, write = counter(src, "pmc_fetch_" + n, "FETCH_SIZE"), counter(src, "pmc_write_" + n, "WRITE_SIZE")
+        want = bench["roofline"]["kernel"]
+        fk = [k for k in fetch if want in k]
+        wk = [k for k in write if want in k]
+        if not (fk and wk):
+            print("%s: no counter pass names %s" % (n, want))
+            continue
+        cfg = bench["config"]
+        V = cfg["rows"] * cfg["cols"] * cfg["batch"]
         check = {}
         for kn, v in fetch.items():
             if "chain_init_theta_kernel" in kn:
-                check = {"kernel": "chain_init_theta_kernel", "bytes_read_known": V * k * 4,
-                         "FETCH_SIZE_KiB": v, "implied_factor": V * k * 4 / (v * 1024.0)}
+                known = V * cfg["k"] * 4
+                check = {"kernel": "chain_init_theta_kernel", "bytes_read_known": known,
+                         "FETCH_SIZE_KiB": v, "implied_factor": known / (v * 1024.0)}
+        rd = fetch[fk[0]] * 1024.0 * 2.0
+        wr = write[wk[0]] * 1024.0
         out = {
-            "command": "rocprofv3 --pmc FETCH_SIZE -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline ; "
-                       "the same with --pmc WRITE_SIZE (separate passes)",
-            "kernel": "admm::" + SWEEP, "workload": WORKLOAD + ", 1 GPU",
+            "command": "rocprofv3 --pmc FETCH_SIZE -- python bench.py --workload '%s' --steps 3 --warmup 1 --no-cpu-baseline ; "
+                       "the same with --pmc WRITE_SIZE (separate passes)" % cfg["workload"],
+            "kernel": fk[0], "workload": cfg["workload"] + ", 1 GPU",
             "FETCH_SIZE_KiB_per_launch": fetch[fk[0]], "WRITE_SIZE_KiB_per_launch": write[wk[0]],
             "fetch_correction": 2.0, "fetch_correction_check": check,
             "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
             "hbm_bytes_per_launch": rd + wr,
-            "algorithmic_bytes_per_launch": V * (32 * k + 16),
+            "stored_bytes_model": bench["roofline"].get("stored_bytes_model"),
+            "algorithmic_bytes_per_launch": bench["roofline"].get("algorithmic_bytes", bench["roofline"].get("bytes_per_launch")),
         }
-        json.dump(out, open(os.path.join(dst, "%s_hbm_traffic_sweep.json" % tag), "w"), indent=1)
-        print(json.dumps(out, indent=1))
+        if dominant is not None:
+            out["kernel_trace"] = {"name": dominant["Name"], "calls": int(dominant["Calls"]),
+                                   "average_ns": float(dominant["AverageNs"]), "percentage": float(dominant["Percentage"])}
+            out["hbm_gbps_at_trace_duration"] = (rd + wr) / float(dominant["AverageNs"])
+        json.dump(out, open(os.path.join(dst, "%s_hbm_traffic_%s.json" % (tag, n)), "w"), indent=1)
+        print(n, json.dumps(out))
 
 
 if __name__ == "__main__":
