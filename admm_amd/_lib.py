@@ -14,6 +14,7 @@ SOLVER_CHAIN_MINSUM = 1
 EXCHANGE_LABELS = 0
 EXCHANGE_DENSE = 1
 COMM_ID_BYTES = 128
+STATIC_LABELS_MAX = 4 << 20
 
 # every symbol include/admm_hip.h declares
 EXPORTS = [
@@ -23,7 +24,7 @@ EXPORTS = [
     "admm_communicate_group", "admm_exchange_counts", "admm_exchange_pack_host",
     "admm_exchange_unpack_host", "admm_update",
     "admm_linear_objective", "admm_objective", "admm_objective_enqueue", "admm_objective_read", "admm_synchronize", "admm_finalize",
-    "admm_download_labels", "admm_download_consensus", "admm_download_state",
+    "admm_download_labels", "admm_download_labels_static", "admm_download_consensus", "admm_download_state",
     "admm_state_size", "admm_partition", "admm_strip_info", "admm_edge_local_info", "admm_edge_local_vertices", "admm_edge_plan",
     "admm_comm_get_unique_id",
     "admm_comm_init", "admm_lcg_fill", "admm_grid_edges", "admm_profile_reset",
@@ -80,6 +81,7 @@ def _load():
         "admm_synchronize": (C.c_int, [vp]),
         "admm_finalize": (C.c_int, [vp]),
         "admm_download_labels": (C.c_int, [vp, ip]),
+        "admm_download_labels_static": (C.c_int, [vp, ip]),
         "admm_download_consensus": (C.c_int, [vp, fp]),
         "admm_download_state": (C.c_int, [vp, C.c_int, fp]),
         "admm_state_size": (C.c_size_t, [vp, C.c_int]),

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -19,9 +20,39 @@
 
 using namespace admm;
 
+// Staging of admm_download_labels_static: device memory that is part of the
+// loaded code object, so the call that uses it never allocates.  Every GPU the
+// library runs on holds its own copy (16 MiB) until the process ends.  Host code
+// never uses this name as an address: scratch_setup() asks the runtime where the
+// current device keeps its copy and only that pointer is handed to kernels and copies.
+static __device__ __align__(256) int32_t scratch[ADMM_STATIC_LABELS_MAX];
+
 namespace {
 
 thread_local std::string g_create_error;
+
+// Where each device keeps its copy of `scratch` (null: not asked yet, or the
+// query failed, see g_scratch_err).
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+int32_t *g_scratch_ptr[kMaxDevices] = {};
+bool g_scratch_asked[kMaxDevices] = {};
+std::string g_scratch_err[kMaxDevices];
+
+// Once per device, with that device current.
+void scratch_setup(int device) {
+  if (device < 0 || device >= kMaxDevices) return;
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (g_scratch_asked[device]) return;
+  g_scratch_asked[device] = true;
+  int32_t *ptr = nullptr;
+  const hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+  if (e != hipSuccess || !ptr) {
+    g_scratch_err[device] = std::string("hipGetSymbolAddress(scratch) failed: ") + hipGetErrorString(e);
+    return;
+  }
+  g_scratch_ptr[device] = ptr;
+}
 
 struct Strip {
   int row0 = 0, nrows = 0, col0 = 0, ncols = 0;
@@ -841,6 +872,7 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
     }                                                                            \
   } while (0)
   if (hipSetDevice(d.device) != hipSuccess) { c->err = "hipSetDevice failed"; return bail(ADMM_E_HIP); }
+  scratch_setup(d.device);  // (a failure only disables admm_download_labels_static on this device)
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(ADMM_E_HIP); }
 
   if (d.solver == ADMM_SOLVER_EDGE_BETHE) {
@@ -2001,6 +2033,27 @@ int admm_download_labels(admm_ctx *c, int32_t *labels) {
   void *stage = nullptr;
   if ((rc = stage_buf(c, &stage, sizeof(int) * (size_t)total))) return rc;
   return decode_labels_into(c, (int *)stage, labels, total);
+}
+
+int admm_download_labels_static(admm_ctx *c, int32_t *labels) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!is_chain(c)) return fail(c, ADMM_E_STATE, "the edge solver decodes no labels");
+  if (!c->inited) return fail(c, ADMM_E_STATE, "download before admm_init");
+  if (!labels) return fail(c, ADMM_E_ARG, "null output");
+  const long long total = (long long)c->d.batch * c->st.nrows * c->d.cols;
+  if (total > (long long)ADMM_STATIC_LABELS_MAX)
+    return fail(c, ADMM_E_ARG, "admm_download_labels_static: this strip has %lld labels, the static staging holds %lld; use admm_download_labels",
+                total, (long long)ADMM_STATIC_LABELS_MAX);
+  const int dev = c->d.device;
+  int32_t *stage = (dev >= 0 && dev < kMaxDevices) ? g_scratch_ptr[dev] : nullptr;
+  if (!stage)
+    return fail(c, ADMM_E_HIP, "admm_download_labels_static: no static staging on device %d (%s)", dev,
+                (dev >= 0 && dev < kMaxDevices && !g_scratch_err[dev].empty()) ? g_scratch_err[dev].c_str() : "device ordinal out of range");
+  if (total == 0) return ADMM_OK;
+  // the decode kernel writes every element it later copies out: nothing of an
+  // earlier call's contents is read
+  return decode_labels_into(c, stage, labels, total);
 }
 
 int admm_download_consensus(admm_ctx *c, float *out) {

@@ -357,6 +357,13 @@ class Grid:
         self._ck(lib.admm_download_labels(self._h, out.ctypes.data_as(_ip)))
         return out[0] if self.batch == 1 else out
 
+    def LabelsStatic(self):
+        """Labels() through the library's fixed staging array: no device allocation."""
+        _, nrows, _, _ = self.StripInfo()
+        out = np.empty((self.batch, nrows, self.cols), dtype=np.int32)
+        self._ck(lib.admm_download_labels_static(self._h, out.ctypes.data_as(_ip)))
+        return out[0] if self.batch == 1 else out
+
     def Consensus(self):
         if self.part == EDGE:
             V = self.EdgeLocalInfo()[2]

@@ -170,6 +170,19 @@ int admm_finalize(admm_ctx *ctx);
  * which is [V][k] on one rank. */
 int admm_download_labels(admm_ctx *ctx, int32_t *labels);
 int admm_download_consensus(admm_ctx *ctx, float *consensus);
+/* admm_download_labels for callers that cannot allocate device memory (a
+ * serving loop that reads the labelling every iteration, a harness that
+ * forbids hipMalloc): it has no counterpart in the reference.  Same output,
+ * same kernel; the device staging between the decode kernel and the copy to
+ * the host is a fixed array inside the library's code object (16 MiB per GPU,
+ * held until the process ends) instead of context memory, and the call makes
+ * no hipMalloc / hipFree.  A strip of more than ADMM_STATIC_LABELS_MAX labels
+ * (batch * strip rows * cols) is refused with ADMM_E_ARG.  All contexts on one
+ * GPU share that array: calls that overlap in time on one GPU (two threads, two
+ * contexts) race; calls one after the other do not, since each waits for its
+ * copy before it returns. */
+#define ADMM_STATIC_LABELS_MAX (4 << 20)
+int admm_download_labels_static(admm_ctx *ctx, int32_t *labels);
 
 /* Solver state for parity tests.  Edge solver (members of class Edge,
  * Tree.h:26-35), this rank's edges: 0 x_mu_node, 1 x_potential_node,

@@ -1,0 +1,54 @@
+"""admm_download_labels_static: the entry point that allocates no device memory, against
+admm_download_labels (bit-exact, both are int32 labels), on two calls in a row, the second
+on a smaller problem: the staging array is shared by every context on the GPU and keeps the
+last call's contents."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _grid(R, Cc, k, seed, batch=1):
+    import admm_amd as A
+    g = A.Grid()
+    g.SetPartitioner(A.ROW)
+    g.SetPenalties(0.5, 1.0)
+    g.SetGlobalInfo(R, Cc, k, batch=batch)
+    g.Generate(seed=seed, pairwise="potts")
+    g.InitOptimization()
+    for _ in range(3):
+        g.Compute(); g.Communicate(); g.Update()
+    return g
+
+
+def test_static_staging_matches_context_staging_twice_second_smaller():
+    big = _grid(300, 517, 16, 7)
+    small = _grid(33, 70, 8, 11, batch=2)
+    want_big, want_small = big.Labels(), small.Labels()
+    assert want_big.max() > 0 and want_small.max() > 0  # not all zeros: stale contents could not pass for these
+    got_big = big.LabelsStatic()
+    got_small = small.LabelsStatic()   # smaller than the call before it: must not see its leftovers
+    assert np.array_equal(got_big, want_big)
+    assert np.array_equal(got_small, want_small)
+    assert np.array_equal(big.LabelsStatic(), want_big)  # and back again
+    big.close(); small.close()
+
+
+def test_static_staging_refuses_what_does_not_fit():
+    import admm_amd as A
+    from admm_amd._lib import STATIC_LABELS_MAX, lib
+    R, Cc = 2049, 2048  # one row more than the array holds
+    assert R * Cc > STATIC_LABELS_MAX
+    g = A.Grid()
+    g.SetPartitioner(A.ROW)
+    g.SetPenalties(0.5, 1.0)
+    g.SetGlobalInfo(R, Cc, 2)
+    g.Load(np.zeros((R * Cc, 2), dtype=np.float32), np.zeros((2, 2), dtype=np.float32))
+    g.InitOptimization()
+    out = np.empty(R * Cc, dtype=np.int32)
+    rc = lib.admm_download_labels_static(g._h, out.ctypes.data_as(C.POINTER(C.c_int32)))
+    assert rc == -1 and b"static staging holds" in lib.admm_last_error(g._h)
+    assert g.Labels().shape == (R, Cc)  # the allocating call still serves it
+    g.close()
