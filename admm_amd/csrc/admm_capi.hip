@@ -118,6 +118,22 @@ struct admm_ctx {
   // counts could leave int16.
   bool lam16 = false;
   int lam16_sweeps = 0, lam16_limit = 32000;
+  // ... and as int8 while every count is known to be far from +-127.  A count moves by at
+  // most one per sweep, so a scan of the arrays that found every |n| below lam8_thr after c
+  // sweeps covers the sweeps up to c + 126 - lam8_thr.  Scans are queued every lam8_every
+  // sweeps; their results travel to pinned host words and are looked at, without waiting,
+  // when a later sweep is queued (a wait happens only when the host has run a cover's whole
+  // length ahead of the device).  The first scan that reports a count at the threshold turns
+  // the arrays into int16, for good.
+  bool lam8 = false;
+  int lam8_thr = 64, lam8_every = 16;
+  int lam8_clean = 0;  // sweeps after which the last clean scan ran
+  struct CountScan { hipEvent_t ev = nullptr; int at = 0; bool pending = false; };
+  static constexpr int kScans = 8;
+  CountScan scans[kScans];
+  int scan_next = 0;
+  int *d_scan_flag = nullptr;  // [kScans], device
+  int *h_scan_flag = nullptr;  // [kScans], pinned host
   size_t lam_slack = 0;                          // floats of slack on either side of a multiplier array
   float *lamf_r = nullptr, *lamf_c = nullptr;    // several strips: binary32 copies, allocated when first needed
   // Labels the sweep reads and writes are bytes (label_t); labels that arrive
@@ -325,16 +341,33 @@ void launch_sweep_t(const ChainArgs &a, int blocks, hipStream_t s) {
   hipLaunchKernelGGL((chain_sweep_kernel<KP, NS, sweep_gpb(KP, NS), sweep_minw(KP, NS), DUAL>), dim3(blocks), dim3(kChainBlock), 0, s, a);
 }
 
-template <int KP>
+template <int KP, bool PCOMP = false>
 void launch_sweep_potts_t(const ChainArgs &a, int blocks, hipStream_t s) {
   // a step needs few registers: four wavefronts per SIMD, operands fetched 8 steps ahead
   // (16 ahead changes nothing: the kernel moves its bytes at the rate a streaming kernel does)
-  hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+  hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, false, PCOMP>), dim3(blocks), dim3(kChainBlock), 0, s, a);
 }
-template <int KP>
-void launch_sweep_potts16_t(const ChainArgs &a, int blocks, hipStream_t s) {
+template <int KP, bool PCOMP = false>
+void launch_sweep_potts16_t(const ChainArgs &a, int blocks, hipStream_t s, bool lam8) {
   // (operands 16 steps ahead instead of 8: 1 to 2 % slower; 32: spills)
-  hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+  if (lam8) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, PCOMP, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+  else hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, PCOMP>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+}
+
+// Path compression in the Potts kernel (the forward pass tracks, per block of eight
+// steps, where every label's path comes from; the trace-back hops over blocks and fills
+// them in with one lane per block): pays when the trace-back is a visible part of the
+// launch and the forward pass has issue slots to spare, i.e. long chains of 32 or 64
+// labels with four wavefronts per SIMD (2048 x 2048, k = 32: trace-back 121 k -> 42 k clock
+// ticks per wavefront of 900 k, forward pass + 2 %: 0.454 -> 0.425 ms per sweep; 2048 x 2048,
+// k = 64: 0.927 -> 0.880 ms; with two wavefronts per SIMD + 3 % to - 3 %).  A lone wavefront per
+// SIMD is bound by the instructions it issues and loses more in the forward pass than
+// the trace-back gives back; eight-label chains are short and already walk eight chains
+// at once.  ADMM_SWEEP_PCOMP=0/1 (tuning and test knob) overrides the choice.
+bool pcomp_chosen(int KP, int waves) {
+  if (KP < 32) return false;
+  if (const char *e = getenv("ADMM_SWEEP_PCOMP")) return atoi(e) != 0;
+  return waves >= 4 * 1024;
 }
 
 // ADMM_SWEEP_POTTS=0 (tuning and test knob) keeps the general kernel on a Potts table.
@@ -377,12 +410,13 @@ int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
     }
   }
   hipStream_t s = c->stream;
+  const bool pcomp = potts && pcomp_chosen(sh.KP, w);
   if (potts && c->lam16) {
     switch (sh.KP) {
-      case 8: launch_sweep_potts16_t<8>(a, blocks, s); break;
-      case 16: launch_sweep_potts16_t<16>(a, blocks, s); break;
-      case 32: launch_sweep_potts16_t<32>(a, blocks, s); break;
-      case 64: launch_sweep_potts16_t<64>(a, blocks, s); break;
+      case 8: launch_sweep_potts16_t<8>(a, blocks, s, c->lam8); break;
+      case 16: launch_sweep_potts16_t<16>(a, blocks, s, c->lam8); break;
+      case 32: if (pcomp) launch_sweep_potts16_t<32, true>(a, blocks, s, c->lam8); else launch_sweep_potts16_t<32>(a, blocks, s, c->lam8); break;
+      case 64: if (pcomp) launch_sweep_potts16_t<64, true>(a, blocks, s, c->lam8); else launch_sweep_potts16_t<64>(a, blocks, s, c->lam8); break;
       default: return fail(c, ADMM_E_ARG, "no sweep kernel for KP=%d", sh.KP);
     }
     HIP_TRY(c, hipGetLastError());
@@ -392,8 +426,8 @@ int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
     switch (sh.KP) {
       case 8: launch_sweep_potts_t<8>(a, blocks, s); break;
       case 16: launch_sweep_potts_t<16>(a, blocks, s); break;
-      case 32: launch_sweep_potts_t<32>(a, blocks, s); break;
-      case 64: launch_sweep_potts_t<64>(a, blocks, s); break;
+      case 32: if (pcomp) launch_sweep_potts_t<32, true>(a, blocks, s); else launch_sweep_potts_t<32>(a, blocks, s); break;
+      case 64: if (pcomp) launch_sweep_potts_t<64, true>(a, blocks, s); else launch_sweep_potts_t<64>(a, blocks, s); break;
       default: return fail(c, ADMM_E_ARG, "no sweep kernel for KP=%d", sh.KP);
     }
     HIP_TRY(c, hipGetLastError());
@@ -448,10 +482,59 @@ void fill_seg_cols(const admm_ctx *c, ChainSeg &s, bool dual) {
 
 int chain_sweep_launch(admm_ctx *c, bool dual);
 
-// int16 counts -> binary32 multipliers: out[i] = in[i] * (penalty / 2), exact
-__global__ void widen_multipliers_kernel(float *__restrict__ out, const int16_t *__restrict__ in, long long n, float hpen) {
+// counts -> binary32 multipliers: out[i] = in[i] * (penalty / 2), exact
+template <typename TC>
+__global__ void widen_multipliers_kernel(float *__restrict__ out, const TC *__restrict__ in, long long n, float hpen) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
     out[i] = (float)in[i] * hpen;
+}
+// int8 counts -> int16 counts
+__global__ void widen_counts_kernel(int16_t *__restrict__ out, const int8_t *__restrict__ in, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    out[i] = in[i];
+}
+// *flag = 1 when some |count| >= thr (16 counts per lane and trip; n is a multiple of 16 or the tail is walked bytewise)
+__global__ __launch_bounds__(256) void scan_counts_kernel(const int8_t *__restrict__ in, long long n, int thr, int *__restrict__ flag) {
+  int hit = 0;
+  const long long n16 = n / 16;
+  const int4 *in4 = reinterpret_cast<const int4 *>(in);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) {
+    const int4 v = in4[i];
+    const int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+#pragma unroll
+      for (int bb = 0; bb < 4; bb++) {
+        const int cnt = (int)(signed char)(w[e] >> (8 * bb));
+        hit |= (cnt >= thr) | (-cnt >= thr);
+      }
+  }
+  for (long long i = n16 * 16 + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    hit |= (in[i] >= thr) | (-in[i] >= thr);
+  if (__builtin_amdgcn_ballot_w64(hit != 0) && (threadIdx.x & 63) == 0) *flag = 1;
+}
+
+// Launches the widening of `n` counts at `in` (int8 or int16, as the context holds them) into binary32.
+void launch_widen_f32(admm_ctx *c, float *out, const float *in, long long n) {
+  const float hpen = c->d.penalty * 0.5f;
+  if (n <= 0) return;
+  if (c->lam8)
+    hipLaunchKernelGGL(widen_multipliers_kernel<int8_t>, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, out, reinterpret_cast<const int8_t *>(in), n, hpen);
+  else
+    hipLaunchKernelGGL(widen_multipliers_kernel<int16_t>, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, out, reinterpret_cast<const int16_t *>(in), n, hpen);
+}
+
+// Second buffers for the multipliers of a context of several strips (one strip has its spare in lam_c).
+int lam_spares(admm_ctx *c, long long nr, long long nc) {
+  if (c->lamf_r) return ADMM_OK;
+  int rc;
+  if ((rc = dev_alloc(c, &c->lamf_r, (size_t)nr + 2 * c->lam_slack)) || (rc = dev_alloc(c, &c->lamf_c, (size_t)nc + 2 * c->lam_slack)))
+    return rc;
+  HIP_TRY(c, hipMemsetAsync(c->lamf_r, 0, sizeof(float) * ((size_t)nr + 2 * c->lam_slack), c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->lamf_c, 0, sizeof(float) * ((size_t)nc + 2 * c->lam_slack), c->stream));
+  c->lamf_r += c->lam_slack;
+  c->lamf_c += c->lam_slack;
+  return ADMM_OK;
 }
 
 // The multipliers as binary32, for readers that take binary32 only.  One strip:
@@ -461,35 +544,120 @@ __global__ void widen_multipliers_kernel(float *__restrict__ out, const int16_t 
 int lam16_widen(admm_ctx *c, const float **fr, const float **fc) {
   const long long nr = (long long)c->d.batch * c->st.nrows * c->d.cols * c->d.k;
   const long long nc = (long long)c->d.batch * c->d.rows * c->st.ncols * c->d.k;
-  const float hpen = c->d.penalty * 0.5f;
   float *dr = c->lam_c, *dc = nullptr;
   if (!c->one_strip()) {
-    if (!c->lamf_r) {
-      int rc;
-      if ((rc = dev_alloc(c, &c->lamf_r, (size_t)nr + 2 * c->lam_slack)) || (rc = dev_alloc(c, &c->lamf_c, (size_t)nc + 2 * c->lam_slack)))
-        return rc;
-      HIP_TRY(c, hipMemsetAsync(c->lamf_r, 0, sizeof(float) * ((size_t)nr + 2 * c->lam_slack), c->stream));
-      HIP_TRY(c, hipMemsetAsync(c->lamf_c, 0, sizeof(float) * ((size_t)nc + 2 * c->lam_slack), c->stream));
-      c->lamf_r += c->lam_slack;
-      c->lamf_c += c->lam_slack;
-    }
+    const int rc = lam_spares(c, nr, nc);
+    if (rc) return rc;
     dr = c->lamf_r;
     dc = c->lamf_c;
   }
-  if (nr > 0)
-    hipLaunchKernelGGL(widen_multipliers_kernel, dim3(grid_for(nr, 256)), dim3(256), 0, c->stream, dr,
-                       reinterpret_cast<const int16_t *>(c->lam_r), nr, hpen);
-  if (dc && nc > 0)
-    hipLaunchKernelGGL(widen_multipliers_kernel, dim3(grid_for(nc, 256)), dim3(256), 0, c->stream, dc,
-                       reinterpret_cast<const int16_t *>(c->lam_c), nc, hpen);
+  launch_widen_f32(c, dr, c->lam_r, nr);
+  if (dc) launch_widen_f32(c, dc, c->lam_c, nc);
   HIP_TRY(c, hipGetLastError());
   *fr = dr;
   *fc = dc ? dc : dr;
   return ADMM_OK;
 }
 
+// int8 counts -> int16 counts, for the rest of the run.
+int lam8_to_16(admm_ctx *c) {
+  const long long nr = (long long)c->d.batch * c->st.nrows * c->d.cols * c->d.k;
+  const long long nc = (long long)c->d.batch * c->d.rows * c->st.ncols * c->d.k;
+  if (c->one_strip()) {
+    // into the buffer the next sweep would write, which then becomes the array
+    if (nr > 0)
+      hipLaunchKernelGGL(widen_counts_kernel, dim3(grid_for(nr, 256)), dim3(256), 0, c->stream,
+                         reinterpret_cast<int16_t *>(c->lam_c), reinterpret_cast<const int8_t *>(c->lam_r), nr);
+    std::swap(c->lam_r, c->lam_c);
+  } else {
+    const int rc = lam_spares(c, nr, nc);
+    if (rc) return rc;
+    if (nr > 0)
+      hipLaunchKernelGGL(widen_counts_kernel, dim3(grid_for(nr, 256)), dim3(256), 0, c->stream,
+                         reinterpret_cast<int16_t *>(c->lamf_r), reinterpret_cast<const int8_t *>(c->lam_r), nr);
+    if (nc > 0)
+      hipLaunchKernelGGL(widen_counts_kernel, dim3(grid_for(nc, 256)), dim3(256), 0, c->stream,
+                         reinterpret_cast<int16_t *>(c->lamf_c), reinterpret_cast<const int8_t *>(c->lam_c), nc);
+    // the old arrays become the spares
+    std::swap(c->lam_r, c->lamf_r);
+    std::swap(c->lam_c, c->lamf_c);
+  }
+  HIP_TRY(c, hipGetLastError());
+  c->lam8 = false;
+  for (auto &sc : c->scans) sc.pending = false;
+  return ADMM_OK;
+}
+
+// Queues a scan of the int8 counts as they stand after `after` sweeps.
+int lam8_queue_scan(admm_ctx *c, int after) {
+  admm_ctx::CountScan &sc = c->scans[c->scan_next];
+  const int slot = c->scan_next;
+  c->scan_next = (c->scan_next + 1) % admm_ctx::kScans;
+  if (sc.pending) {  // the oldest scan still unread: read it first (it completed long ago)
+    HIP_TRY(c, hipEventSynchronize(sc.ev));
+    if (c->h_scan_flag[slot]) return lam8_to_16(c);
+    c->lam8_clean = std::max(c->lam8_clean, sc.at);
+    sc.pending = false;
+  }
+  if (!sc.ev) HIP_TRY(c, hipEventCreateWithFlags(&sc.ev, hipEventDisableTiming));
+  const long long nr = (long long)c->d.batch * c->st.nrows * c->d.cols * c->d.k;
+  const long long nc = (long long)c->d.batch * c->d.rows * c->st.ncols * c->d.k;
+  HIP_TRY(c, hipMemsetAsync(c->d_scan_flag + slot, 0, sizeof(int), c->stream));
+  if (nr > 0)
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(grid_for(nr / 16 + 1, 256)), dim3(256), 0, c->stream,
+                       reinterpret_cast<const int8_t *>(c->lam_r), nr, c->lam8_thr, c->d_scan_flag + slot);
+  if (!c->lam_shared() && nc > 0)
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(grid_for(nc / 16 + 1, 256)), dim3(256), 0, c->stream,
+                       reinterpret_cast<const int8_t *>(c->lam_c), nc, c->lam8_thr, c->d_scan_flag + slot);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(c->h_scan_flag + slot, c->d_scan_flag + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipEventRecord(sc.ev, c->stream));
+  sc.at = after;
+  sc.pending = true;
+  return ADMM_OK;
+}
+
+// Before sweep number `s` (0-based) is queued on int8 counts: make sure a clean scan covers it.
+int lam8_cover(admm_ctx *c, int s) {
+  const int reach = 126 - c->lam8_thr;  // sweeps a clean scan covers
+  // results that have arrived by now, oldest first
+  for (int pass = 0; pass < 2 && c->lam8; pass++) {
+    const bool must = pass == 1;
+    if (must && s - c->lam8_clean <= reach) break;
+    for (int i = 0; i < admm_ctx::kScans && c->lam8; i++) {
+      const int slot = (c->scan_next + i) % admm_ctx::kScans;
+      admm_ctx::CountScan &sc = c->scans[slot];
+      if (!sc.pending) continue;
+      if (must) {
+        if (s - c->lam8_clean <= reach) break;
+        HIP_TRY(c, hipEventSynchronize(sc.ev));
+      } else if (hipEventQuery(sc.ev) != hipSuccess) {
+        break;  // the later ones have not completed either
+      }
+      if (c->h_scan_flag[slot]) return lam8_to_16(c);
+      c->lam8_clean = std::max(c->lam8_clean, sc.at);
+      sc.pending = false;
+    }
+  }
+  if (c->lam8 && s - c->lam8_clean > reach) {
+    // nothing pending reaches far enough: scan now and wait for it
+    int rc = lam8_queue_scan(c, s);
+    if (rc || !c->lam8) return rc;
+    return lam8_cover(c, s);
+  }
+  return ADMM_OK;
+}
+
 int chain_sweep(admm_ctx *c, bool dual) {
+  if (!dual && c->lam8) {
+    const int rc = lam8_cover(c, c->lam16_sweeps);
+    if (rc) return rc;
+  }
   if (!dual && c->lam16 && c->lam16_sweeps >= c->lam16_limit) {
+    if (c->lam8) {
+      const int rc8 = lam8_to_16(c);
+      if (rc8) return rc8;
+    }
     // a count could leave int16 from here on: binary32 for the rest of the run
     const float *fr = nullptr, *fc = nullptr;
     const int rc = lam16_widen(c, &fr, &fc);
@@ -507,6 +675,7 @@ int chain_sweep(admm_ctx *c, bool dual) {
   // the row chains wrote the updated multipliers into the other buffer
   if (!rc && !dual && c->lam_shared()) std::swap(c->lam_r, c->lam_c);
   if (!rc && !dual && c->lam16) c->lam16_sweeps++;
+  if (!rc && !dual && c->lam8 && c->lam16_sweeps % c->lam8_every == 0) return lam8_queue_scan(c, c->lam16_sweeps);
   return rc;
 }
 
@@ -945,8 +1114,8 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
         (rc = dev_alloc(c, &c->xo_r, nrow_nodes)) || (rc = dev_alloc(c, &c->xo_c, ncol_nodes)) ||
         // (+ 16 bytes per step: the Potts kernel's layout is per wavefront, and its last
         // wavefront may hold a single chain of 8 labels)
-        (rc = dev_alloc(c, &c->bp_r, B * c->st.nrows * Tp_r * c->KP + 16 * Tp_r + 16)) ||
-        (rc = dev_alloc(c, &c->bp_c, B * c->st.ncols * Tp_c * c->KP + 16 * Tp_c + 16)) ||
+        (rc = dev_alloc(c, &c->bp_r, B * c->st.nrows * Tp_r * c->KP + 24 * Tp_r + 64)) ||
+        (rc = dev_alloc(c, &c->bp_c, B * c->st.ncols * Tp_c * c->KP + 24 * Tp_c + 64)) ||
         (rc = dev_alloc(c, &c->d_W, k * k)) || (rc = dev_alloc(c, &c->d_Wsplit, k * k)) ||
         (rc = dev_alloc(c, &c->d_Wt, k * k)) || (rc = dev_alloc(c, &c->d_WsplitT, k * k)) ||
         (rc = dev_alloc(c, &c->d_WtT, k * k)) ||
@@ -990,6 +1159,8 @@ int admm_destroy(admm_ctx *c) {
   if (c->ev_packed) (void)hipEventDestroy(c->ev_packed);
   if (c->ev_pulled) (void)hipEventDestroy(c->ev_pulled);
   for (auto &pr : c->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (auto &sc : c->scans) if (sc.ev) (void)hipEventDestroy(sc.ev);
+  if (c->h_scan_flag) (void)hipHostFree(c->h_scan_flag);
   for (void *p : c->allocs) (void)hipFree(p);
   if (c->d_stage) (void)hipFree(c->d_stage);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1283,6 +1454,19 @@ int admm_init(admm_ctx *c) {
       c->lam16 = potts && c->KP >= 8 && potts_enabled() && pow2 && !(e16 && atoi(e16) == 0);
       c->lam16_sweeps = 0;
       c->lam16_limit = elim ? std::max(0, std::min(32000, atoi(elim))) : 32000;
+      // int8 counts: ADMM_LAM8=0 never; ADMM_LAM8_THR / ADMM_LAM8_EVERY move the scan's threshold and
+      // spacing (test knobs: a threshold of 1 or 2 makes a short run go through the change to int16)
+      const char *e8 = getenv("ADMM_LAM8"), *ethr = getenv("ADMM_LAM8_THR"), *eev = getenv("ADMM_LAM8_EVERY");
+      c->lam8 = c->lam16 && !(e8 && atoi(e8) == 0);
+      c->lam8_thr = ethr ? std::max(1, std::min(100, atoi(ethr))) : 64;
+      c->lam8_every = eev ? std::max(1, std::min(126 - c->lam8_thr, atoi(eev))) : 16;
+      c->lam8_clean = 0;
+      for (auto &sc : c->scans) sc.pending = false;
+      if (c->lam8 && !c->d_scan_flag) {
+        int rc8;
+        if ((rc8 = dev_alloc(c, &c->d_scan_flag, (size_t)admm_ctx::kScans))) return rc8;
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_scan_flag, sizeof(int) * admm_ctx::kScans, hipHostMallocDefault));
+      }
     }
   }
   HIP_TRY(c, hipStreamSynchronize(s));
@@ -2126,9 +2310,7 @@ int admm_download_state(admm_ctx *c, int which, float *out) {
       case 10: case 11:
         if (c->lam16) {
           if ((rc = stage_buf(c, &tmp, sizeof(float) * n))) return rc;
-          hipLaunchKernelGGL(widen_multipliers_kernel, dim3(grid_for((long long)n, 256)), dim3(256), 0, c->stream,
-                             (float *)tmp, reinterpret_cast<const int16_t *>((which == 10 || c->lam_shared()) ? c->lam_r : c->lam_c),
-                             (long long)n, c->d.penalty * 0.5f);
+          launch_widen_f32(c, (float *)tmp, (which == 10 || c->lam_shared()) ? c->lam_r : c->lam_c, (long long)n);
           src = tmp;
         } else {
           src = (which == 10 || c->lam_shared()) ? c->lam_r : c->lam_c;
@@ -2222,10 +2404,14 @@ int admm_sweep_kernel_name(admm_ctx *c, char *buf, int len) {
   if (!buf || len < 1) return fail(c, ADMM_E_ARG, "null buffer");
   SweepShape sh = pick_shape(c->KP, (long long)c->d.batch * ((long long)c->st.nrows + c->st.ncols));
   const bool potts = potts_chosen(c, sh);
-  if (potts)
-    snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, 1, 8, 4, false, true, %s>", sh.KP, c->lam16 ? "true" : "false");
-  else
-    snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, %d, %d, %d, false, false, false>", sh.KP, sh.NS, sweep_gpb(sh.KP, sh.NS), sweep_minw(sh.KP, sh.NS));
+  if (potts) {
+    // the same count of wavefronts launch_sweep works out
+    const int CPW = 64 / sh.KP;
+    const int waves = 2 * ((c->d.batch * c->st.nrows + CPW - 1) / CPW) + 2 * ((c->d.batch * c->st.ncols + CPW - 1) / CPW);
+    snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, 1, 8, 4, false, true, %s, %s, %s>", sh.KP, c->lam16 ? "true" : "false",
+             pcomp_chosen(sh.KP, waves) ? "true" : "false", (c->lam16 && c->lam8) ? "true" : "false");
+  } else
+    snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, %d, %d, %d, false, false, false, false, false>", sh.KP, sh.NS, sweep_gpb(sh.KP, sh.NS), sweep_minw(sh.KP, sh.NS));
   return ADMM_OK;
 }
 

@@ -252,6 +252,9 @@ constexpr unsigned long long kFieldLsb = W >= 64 ? 1ull : (~0ull / ((1ull << (W 
 // MINW : wavefronts per SIMD the register allocation must leave room for
 // DUAL : evaluate the chain minimum under theta + lambda only (no dual
 //        update, no back-pointers, no labels)
+// PCOMP: Potts step with path compression for the trace-back (see there)
+// LAM8 : with LAM16, the counts are int8: the host runs these kernels while it knows
+//        every count to be far from +-127 (it scans the arrays every few sweeps)
 // LAM16: the multiplier arrays hold int16 counts n with lambda = n * penalty / 2.
 //        Every update adds -penalty/2, 0 or +penalty/2, so when penalty is a power
 //        of two and the counts stay below 2^15 the binary32 sums are exact multiples
@@ -264,8 +267,12 @@ constexpr unsigned long long kFieldLsb = W >= 64 ? 1ull : (~0ull / ((1ull << (W 
 // straight from registers, dword (t/4)*KP + b of the half chain's scratch;
 // the backtrack streams them back one 64-step chunk at a time (t counts the
 // steps of the half chain in sweep order).
-template <int KP, int NS, int GPB, int MINW, bool DUAL, bool POTTS = false, bool LAM16 = false>
+template <int KP, int NS, int GPB, int MINW, bool DUAL, bool POTTS = false, bool LAM16 = false, bool PCOMP = false, bool LAM8 = false>
 __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const ChainArgs args) {
+  static_assert(!PCOMP || POTTS, "path compression belongs to the Potts step");
+  static_assert(!LAM8 || LAM16, "LAM8: the counts of LAM16, one byte each");
+  typedef typename std::conditional<LAM8, int8_t, int16_t>::type count_t;
+  constexpr unsigned CB = sizeof(count_t);  // bytes per count
   static_assert(!POTTS || (NS == 1 && !DUAL), "the Potts step keeps a label's message in its one lane");
   static_assert(!LAM16 || (NS == 1 && !DUAL), "int16 multipliers: one step per load group, never the dual evaluation");
   constexpr int LPC = KP * NS;   // lanes per chain
@@ -299,7 +306,17 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   __shared__ int s_joinx[WPB / 2][CPW];        // label of the left halves' last node, from the join
   __shared__ int s_x[WPB][CPW][kChunk];
   __shared__ int s_xo[WPB][CPW][kChunk];
-  __shared__ __attribute__((aligned(16))) uint32_t s_bp[WPB][CPW][16 * KP];
+  __shared__ __attribute__((aligned(16))) uint32_t s_bp[WPB][CPW][PCOMP ? 1 : 16 * KP];
+  // Trace-back of the Potts step (see there): a round's step records, transposed so that one
+  // lane per block of eight steps reads its block's, then the round's labels
+  constexpr int TB_RSTEPS = KP == 64 ? 256 : 512 / CPW;     // steps of every chain that one round covers
+  constexpr int TB_NBR = TB_RSTEPS / 8;                      // blocks of eight steps per chain and round
+  constexpr int TB_NW = CPW * TB_NBR;                        // walking lanes: 32 (64 labels) or 64
+  constexpr int TB_SW = TB_NW == 64 ? 72 : 40;               // row pitch that keeps both the transposed writes and the reads free of bank conflicts
+  constexpr int TB_NA = KP == 64 ? 3 : (KP == 32 ? 2 : 1);   // dwords per record: keep field (one or two), i1 (packed into the field's dword up to 16 labels)
+  constexpr int TB_W = TB_NA * 8 * TB_SW;
+  static_assert(!PCOMP || TB_W >= CPW * TB_RSTEPS, "the round's labels reuse the record staging");
+  __shared__ __attribute__((aligned(16))) uint32_t s_tb[WPB][PCOMP ? TB_W : 4];
 
   const int lane = threadIdx.x & 63;
   // the wavefront index is the same in all 64 lanes: keep it (and what
@@ -388,6 +405,20 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // once per chunk: 16 bytes per step and wavefront instead of one per label.
   int vk0 = 0, vk1 = 0, ve0 = 0, ve1 = 0;
   float Mreg = bvalid ? 0.0f : INF;  // A_{-1}: min(0, 0 + w) = 0 makes the first step M_0 = t_0
+  // Path compression for the trace-back.  The back-pointer of a Potts step is "keep the
+  // label, or go to i1", so the composition of the back-pointers of a block of eight steps,
+  //   F(b) = label at the node before the block when its last node has label b,
+  // follows the recursion  F <- keep[b] ? F[b] : F[i1]  step by step: one cross-lane fetch
+  // of lane i1's value and one select, off the recursion's own dependency chain (the fetch
+  // is consumed one step later).  F is kept as the LANE that holds the label (so that the
+  // trace-back can use it as a lane select), restarted as the identity every eight steps
+  // and recorded, one byte per block, four blocks to a dword.  The trace-back then hops
+  // over the records (an eighth of the steps, two scalar instructions each) and fills in the
+  // labels inside all blocks at once, one lane per block.
+  int org = lane;
+  int org_pend = lane;
+  unsigned long long keep_pend = ~0ull;
+  uint32_t rec = 0;
 
   if constexpr (RECOMP) {
     // every wavefront of the block writes the whole table (same values), so
@@ -422,29 +453,37 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // (int16 counts: the same element offsets, two bytes each)
   float *const lam_out_or_in = sg.lam_out ? sg.lam_out : const_cast<float *>(sg.lam);
   const __amdgpu_buffer_rsrc_t lam_rs = __builtin_amdgcn_make_buffer_rsrc(
-      LAM16 ? (void *)(reinterpret_cast<int16_t *>(const_cast<float *>(sg.lam)) + base_el) : (void *)const_cast<float *>(sg.lam + base_el),
+      LAM16 ? (void *)(reinterpret_cast<count_t *>(const_cast<float *>(sg.lam)) + base_el) : (void *)const_cast<float *>(sg.lam + base_el),
       0, 0xFFFFFFFF, kRsrcWord3);
   const __amdgpu_buffer_rsrc_t lamo_rs = __builtin_amdgcn_make_buffer_rsrc(
-      LAM16 ? (void *)(reinterpret_cast<int16_t *>(lam_out_or_in) + base_el) : (void *)(lam_out_or_in + base_el),
+      LAM16 ? (void *)(reinterpret_cast<count_t *>(lam_out_or_in) + base_el) : (void *)(lam_out_or_in + base_el),
       0, 0xFFFFFFFF, kRsrcWord3);
   const unsigned lam_sign = sg.lam_sign;
   // int16 counts: count * (+-penalty / 2) is the multiplier with the set's sign on it
   const float shpen = lam_sign ? -hpen : hpen;
-  const unsigned sstep_l = rev ? 0u - 2u * nstride : 2u * nstride;
-  const unsigned soff0_l = rev ? 2u * nstride * (reach - (unsigned)(NS - 1)) : 0u;
+  const unsigned sstep_l = rev ? 0u - CB * nstride : CB * nstride;
+  const unsigned soff0_l = rev ? CB * nstride * (reach - (unsigned)(NS - 1)) : 0u;
   // the lane's own step of group 0, in bytes
   const unsigned lane_off = 4u * ((unsigned)((first - first0) * k) + (unsigned)(rev ? NS - 1 - s : s) * nstride + (unsigned)b);
   // Stores of lanes that own no label (padding past k, the duplicate of a
   // clamped chain) get an offset beyond the descriptor's range, which the
   // hardware drops: no branch around the store.
-  const unsigned lane_off_st = (lvalid && sg.lam_out) ? (LAM16 ? lane_off >> 1 : lane_off) : 0xFFFFFFFFu;
+  const unsigned lane_off_c = LAM8 ? lane_off >> 2 : lane_off >> 1;  // the lane's offset in an array of counts
+  const unsigned lane_off_st = (lvalid && sg.lam_out) ? (LAM16 ? lane_off_c : lane_off) : 0xFFFFFFFFu;
+  auto count_store = [&](const int n, const unsigned step) {
+    if constexpr (LAM8) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)n, lamo_rs, lane_off_st, soff0_l + step * sstep_l, 0);
+    else __builtin_amdgcn_raw_buffer_store_b16((short)n, lamo_rs, lane_off_st, soff0_l + step * sstep_l, 0);
+  };
   auto buf_load = [&](const __amdgpu_buffer_rsrc_t &r, unsigned soff) -> float {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_off, soff, 0));
   };
   // a multiplier: binary32, or (LAM16) the int16 count, sign-extended, as the bits of the float
   auto lam_load = [&](unsigned step) -> float {
-    if constexpr (LAM16) {
-      const short n = __builtin_bit_cast(short, __builtin_amdgcn_raw_buffer_load_b16(lam_rs, lane_off >> 1, soff0_l + step * sstep_l, 0));
+    if constexpr (LAM8) {
+      const signed char n = __builtin_bit_cast(signed char, __builtin_amdgcn_raw_buffer_load_b8(lam_rs, lane_off_c, soff0_l + step * sstep_l, 0));
+      return __int_as_float((int)n);
+    } else if constexpr (LAM16) {
+      const short n = __builtin_bit_cast(short, __builtin_amdgcn_raw_buffer_load_b16(lam_rs, lane_off_c, soff0_l + step * sstep_l, 0));
       return __int_as_float((int)n);
     } else {
       return buf_load(lam_rs, soff0 + step * sstep);
@@ -458,6 +497,8 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   uint32_t *bpchain = DUAL ? nullptr : reinterpret_cast<uint32_t *>(sg.bp) + ((long long)chain * 2 + rev) * (TpadH / 4) * KP;
   // Potts step: the wavefront's share of the scratch, [half][chunk][4][64] dwords
   uint32_t *bpwave = DUAL ? nullptr : reinterpret_cast<uint32_t *>(sg.bp) + (long long)chain0 * 2 * (TpadH / 4) * KP + (long long)rev * 4 * TpadH;
+  // ... and of the block records behind the masks of both halves: [32 steps][64] dwords
+  uint32_t *bprec = DUAL ? nullptr : reinterpret_cast<uint32_t *>(sg.bp) + (long long)chain0 * 2 * (TpadH / 4) * KP + 8LL * TpadH + (long long)rev * 2 * TpadH;
   // the same scratch for the stores of the forward pass: descriptor at the
   // wavefront's first chain, the lane's chain and label as a fixed offset
   const __amdgpu_buffer_rsrc_t bp_rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -585,12 +626,49 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     }
   };
 
+  // Potts step, path compression: the select that finishes the previous step's update
+  // (`after`: a value the select must not be scheduled ahead of -- left to itself the
+  // compiler hoists it to right behind the fetch and then waits for the fetch there)
+  auto origin_settle = [&](const unsigned long long after) {
+    asm("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(org) : "v"(org_pend), "s"(keep_pend), "s"(after));
+  };
+  // ... one step: eq's lowest lane of this lane's chain is i1; fetch that lane's value now,
+  // select it (where the label is not kept) when the next step comes by
+  const int cbase = cs * LPC, cbase4 = cbase << 2;
+  auto origin_step = [&](const unsigned long long eq, const unsigned long long keepm) {
+    origin_settle(keepm);
+    if constexpr (KP == 64) {
+      org_pend = __builtin_amdgcn_readlane(org, __builtin_ctzll(eq));
+    } else {
+      const unsigned field = (unsigned)(eq >> cbase);  // the chain's field has a bit set
+      int src;  // byte address of the lane: (i1 << 2) | (first lane of the chain << 2)
+      asm("v_lshl_or_b32 %0, %1, 2, %2" : "=v"(src) : "v"(__builtin_ctz(field)), "v"(cbase4));
+      org_pend = __builtin_amdgcn_ds_bpermute(src, org);
+    }
+    keep_pend = keepm;
+  };
+  // ... a block of eight steps starts at step tb: record the block before it, restart
+  auto origin_block = [&](const int tb) {
+    origin_settle(keep_pend);
+    keep_pend = ~0ull;
+    if (tb > 0) {
+      rec = __builtin_amdgcn_alignbit((unsigned)org, rec, 8);
+      const int r = (tb >> 3) - 1;
+      if ((r & 3) == 3) bprec[(r >> 2) * 64 + lane] = rec;
+    }
+    org = lane;
+  };
+
   // One unrolled block of BLK steps starting at step tb (tt0 = tb - chunk start).
   // The order inside a step is pinned with scheduling barriers: LDS reads
   // first, then the previous step's arg-min (it covers the LDS latency), then
   // the min-plus of this step.
   auto block = [&](const int tb, const int tt0, auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
+    if constexpr (PCOMP) {
+      static_assert(!PCOMP || BLK == 8, "the trace-back's records are one per unrolled block of eight steps");
+      origin_block(tb);
+    }
     int xown = -1, xoth = -1;  // labels of the current group (own step of this lane)
     if (!DUAL) {
       xown = s_x[wib][cs][tt0 + s];
@@ -642,10 +720,8 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
           unary_acc += (double)sel0;
           unary_acc += (double)sel1;
           // (stored by the sets that keep their own array, where sgn = 1 and m is the new count)
-          if (FULL || tg < T)
-            __builtin_amdgcn_raw_buffer_store_b16((short)m0, lamo_rs, lane_off_st, soff0_l + (unsigned)tg * sstep_l, 0);
-          if (FULL || tg + 1 < T)
-            __builtin_amdgcn_raw_buffer_store_b16((short)m1, lamo_rs, lane_off_st, soff0_l + (unsigned)(tg + 1) * sstep_l, 0);
+          if (FULL || tg < T) count_store(m0, (unsigned)tg);
+          if (FULL || tg + 1 < T) count_store(m1, (unsigned)(tg + 1));
         } else {
           th_own = th_pair;
         }
@@ -666,8 +742,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         const float la = lam_in + p;                          // Tree.cpp:70
         if constexpr (LAM16) {
           const int n_out = n_in + (int)(xown == b) - (int)(xoth == b);
-          if (FULL || tg + s < T)
-            __builtin_amdgcn_raw_buffer_store_b16((short)n_out, lamo_rs, lane_off_st, soff0_l + (unsigned)tg * sstep_l, 0);
+          if (FULL || tg + s < T) count_store(n_out, (unsigned)tg);
         } else {
           if (FULL || tg + s < T) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(la), lamo_rs, lane_off_st, goff, 0);
         }
@@ -753,6 +828,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
                 : "+v"(vk0), "+v"(vk1), "+v"(ve0), "+v"(ve1)
                 : "s"((unsigned)keepm), "s"((unsigned)(keepm >> 32)), "s"((unsigned)eq), "s"((unsigned)(eq >> 32)), "s"(ls));
             Mreg = th_own + __builtin_amdgcn_fmed3f(Mreg, C1, potts_pad);
+            if constexpr (PCOMP) origin_step(eq, keepm);
           }
         } else if (live) {
           float c[A];
@@ -866,6 +942,17 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     }
   }
 
+  if constexpr (PCOMP) {
+    // the last block's record (steps past the chain's end left F as it was), in its place in
+    // a whole dword
+    origin_settle(keep_pend);
+    if (T > 0) {
+      rec = __builtin_amdgcn_alignbit((unsigned)org, rec, 8);
+      int r = ((T + 7) >> 3) - 1;
+      for (; (r & 3) != 3; r++) rec >>= 8;
+      bprec[(r >> 2) * 64 + lane] = rec;
+    }
+  }
   // the last block's final position is still pending
   if (!DUAL && PIPE) {
     const int tb_last = ((T - 1) / BLK) * BLK;
@@ -962,6 +1049,207 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // copy while the chunk before it is already being fetched into registers
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // this wavefront's own back-pointer stores
   const int nchunks = Tpad / kChunk;
+  if constexpr (PCOMP) {
+    // Trace-back of the Potts step with path compression.  The forward pass left, per step, the two lane masks
+    // keep and eq (lane = step of a 64-step chunk) and, per block of eight steps, the record
+    // F of the block (see "path compression" above).  In pieces of 512 steps, from the end:
+    //   1. hop over the piece's 64 records on the scalar unit,
+    //        x <- byte (record j) of lane x's dword,
+    //      which leaves the label at the last node of every block (kept as the lane that
+    //      holds it, lane j of one register per chain);
+    //   2. in rounds of TB_RSTEPS steps, lane (chain, block) walks its block's eight steps,
+    //        x <- bit x of keep ? x : i1,
+    //      on records staged through LDS in transposed order ([step of the block][lane]), and
+    //      leaves the eight labels in LDS;
+    //   3. the lanes pick the labels up step by step again, store them and gather the
+    //      pairwise terms of the linear objective.
+    // The serial part is a step of two scalar instructions per eight nodes plus eight
+    // steps per round, instead of one step per node.
+    uint32_t *tbs = &s_tb[wib][0];
+    int cur[CPW], carry[CPW];
+    double linc[CPW];
+    float wp[CPW];
+    label_t *xcb[CPW];  // uniform base pointers of the chains of this wavefront
+    bool cval[CPW];
+#pragma unroll
+    for (int q = 0; q < CPW; q++) {
+      cur[q] = q * KP + __builtin_amdgcn_readlane(bi, q * LPC);  // lane holding the chain's last label
+      carry[q] = __builtin_amdgcn_readlane(xjoin, q * LPC);      // used by the right half only
+      linc[q] = 0.0;
+      wp[q] = 0.0f;
+      const int craw = (wlocal >> 1) * CPW + q;
+      cval[q] = craw < sg.nchains;
+      const int cq = cval[q] ? craw : sg.nchains - 1;
+      xcb[q] = sg.x + (long long)cq * Tfull + (rev ? Tfull - 1 : 0);
+    }
+    const int nrec = (T + 7) >> 3;
+    constexpr int NCK = TB_RSTEPS / 64;
+    // Records and masks are fetched one stage ahead, into the registers the stage before has
+    // just finished with: the next piece's records behind the hop over this piece's, the
+    // next round's masks behind the staging of this round's.
+    uint32_t recs[16];
+    uint32_t mk[NCK][4];
+    auto load_recs = [&](const int sc) {
+      const int rec0 = sc << 6;
+      const int nr = min(64, nrec - rec0);
+#pragma unroll
+      for (int d = 0; d < 16; d++) recs[d] = (4 * d < nr) ? bprec[((rec0 >> 2) + d) * 64 + lane] : 0u;
+    };
+    auto load_masks = [&](const int tr0) {
+#pragma unroll
+      for (int ck = 0; ck < NCK; ck++) {
+        const int chunk = (tr0 >> 6) + ck;
+        const uint32_t *src = bpwave + (long long)chunk * 256 + lane;
+#pragma unroll
+        for (int i = 0; i < 4; i++) mk[ck][i] = (chunk * kChunk < T) ? src[i * 64] : 0u;
+      }
+    };
+    const int nrounds = (T + TB_RSTEPS - 1) / TB_RSTEPS;
+    load_recs((nrec - 1) >> 6);
+    load_masks((nrounds - 1) * TB_RSTEPS);
+    __builtin_amdgcn_sched_barrier(0);
+    int xe[CPW];
+#pragma unroll
+    for (int q = 0; q < CPW; q++) xe[q] = 0;
+    for (int g = nrounds - 1; g >= 0; g--) {
+      const int tr0 = g * TB_RSTEPS;
+      const int sc = tr0 >> 9;
+      const int rec0 = sc << 6;
+      if (g == nrounds - 1 || ((tr0 + TB_RSTEPS) & 511) == 0) {
+        // 1. a new piece: labels at its blocks' last nodes
+        const int nr = min(64, nrec - rec0);
+        static_for<0, 64>([&](auto r_c) {
+          constexpr int j = 63 - decltype(r_c)::value;
+          if (j < nr) {
+#pragma unroll
+            for (int q = 0; q < CPW; q++) {
+              const int cu = __builtin_amdgcn_readfirstlane(cur[q]);  // already uniform: keeps it scalar
+              asm("v_writelane_b32 %0, %1, %2" : "+v"(xe[q]) : "s"(cu), "n"(j));
+              const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)recs[j >> 2], cu);
+              cur[q] = (int)((w >> ((j & 3) * 8)) & 0xffu);
+            }
+          }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        if (sc > 0) load_recs(sc - 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      {
+        // 2. and 3. for the round
+        wave_lds_fence();
+#pragma unroll
+        for (int ck = 0; ck < NCK; ck++) {
+#pragma unroll
+          for (int q = 0; q < CPW; q++) {
+            const int at = (lane & 7) * TB_SW + q * TB_NBR + ck * 8 + (lane >> 3);
+            if constexpr (KP == 64) {
+              const unsigned long long ef = mk[ck][2] | ((unsigned long long)mk[ck][3] << 32);
+              tbs[at] = mk[ck][0];
+              tbs[8 * TB_SW + at] = mk[ck][1];
+              // at the chain's first node the masks are not used (whatever they hold gives a label below KP)
+              tbs[16 * TB_SW + at] = (uint32_t)__builtin_ctzll(ef | (1ull << 63));
+            } else {
+              constexpr uint32_t FM = KP >= 32 ? 0xFFFFFFFFu : (1u << (KP & 31)) - 1u;
+              const uint32_t kf = ((q * KP < 32 ? mk[ck][0] : mk[ck][1]) >> ((q * KP) & 31)) & FM;
+              const uint32_t ef = ((q * KP < 32 ? mk[ck][2] : mk[ck][3]) >> ((q * KP) & 31)) & FM;
+              const uint32_t i1 = (uint32_t)__builtin_ctz(ef | (1u << (KP - 1)));
+              if constexpr (KP == 32) {
+                tbs[at] = kf;
+                tbs[8 * TB_SW + at] = i1;
+              } else {
+                tbs[at] = kf | (i1 << 16);
+              }
+            }
+          }
+        }
+        wave_lds_fence();
+        __builtin_amdgcn_sched_barrier(0);
+        if (g > 0) load_masks(tr0 - TB_RSTEPS);
+        __builtin_amdgcn_sched_barrier(0);
+        // the walking lane's chain, block and first label (the shuffles need every lane)
+        const int wq = lane / TB_NBR, wblk = lane % TB_NBR;
+        const int gb = (tr0 >> 3) + wblk;  // block of the half chain
+        int xs = 0;
+#pragma unroll
+        for (int q = 0; q < CPW; q++) {
+          const int v = __shfl(xe[q], (gb - rec0) & 63) - q * KP;
+          xs = (wq == q) ? v : xs;
+        }
+        uint32_t lab[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) lab[e] = 0u;
+        if (lane < TB_NW) {
+          const int s0 = T - 1 - 8 * gb;  // the block's last live step; negative: the block lies past the chain's end
+          uint32_t ra[8], rb[8], rc[8];
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            ra[e] = tbs[e * TB_SW + lane];
+            rb[e] = TB_NA >= 2 ? tbs[8 * TB_SW + e * TB_SW + lane] : 0u;
+            rc[e] = TB_NA >= 3 ? tbs[16 * TB_SW + e * TB_SW + lane] : 0u;
+          }
+          int x = xs;
+#pragma unroll
+          for (int e = 7; e >= 0; e--) {
+            const bool on = e <= s0;
+            lab[e] = on ? (uint32_t)x : 0u;
+            if (e > 0) {
+              // x <- bit x of keep ? x : i1, branch-free
+              int kept, i1;
+              if constexpr (KP == 64) {
+                kept = (int)(((ra[e] | ((unsigned long long)rb[e] << 32)) >> x) & 1ull);
+                i1 = (int)rc[e];
+              } else if constexpr (KP == 32) {
+                kept = (int)((ra[e] >> x) & 1u);
+                i1 = (int)rb[e];
+              } else {
+                kept = (int)((ra[e] >> x) & 1u);
+                i1 = (int)(ra[e] >> 16);
+              }
+              const int nx = kept ? x : i1;
+              x = on ? nx : x;
+            }
+          }
+        }
+        wave_lds_fence();
+        if (lane < TB_NW) {
+          uint4 *dst = reinterpret_cast<uint4 *>(tbs + wq * TB_RSTEPS + wblk * 8);
+          dst[0] = uint4{lab[0], lab[1], lab[2], lab[3]};
+          dst[1] = uint4{lab[4], lab[5], lab[6], lab[7]};
+        }
+        wave_lds_fence();
+        // labels out, and the round's terms of the linear objective
+#pragma unroll
+        for (int ck = NCK - 1; ck >= 0; ck--) {
+          const int t0 = tr0 + ck * kChunk;
+          if (t0 >= T) continue;
+          const int n = min(kChunk, T - t0);
+#pragma unroll
+          for (int q = 0; q < CPW; q++) {
+            linc[q] += (double)wp[q];
+            const int xi = (int)tbs[q * TB_RSTEPS + ck * kChunk + lane];
+            int xn = __shfl_down(xi, 1);
+            xn = (lane == n - 1) ? carry[q] : xn;
+            const int t = t0 + lane;
+            wp[q] = 0.0f;
+            if (lane < n) {
+              if (cval[q]) xcb[q][xdir * t] = (label_t)xi;
+              if (t + 1 < Tedge) wp[q] = Wsp[xi * k + xn];
+            }
+            carry[q] = __builtin_amdgcn_readlane(xi, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < CPW; q++) {
+      double l = linc[q] + (double)wp[q];
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) l += __shfl_xor(l, d);
+      if (cval[q] && lane == 0) sg.chain_lin[2 * ((wlocal >> 1) * CPW + q) + rev] = l;
+    }
+    if (args.stamps && lane == 0) args.stamps[3 * (size_t)wave + 2] = __builtin_readcyclecounter();
+    return;
+  }
   if constexpr (POTTS && CPW >= 2) {
     // Two or more chains per wavefront: one lane per chain walks.  Lane tt
     // (= step tt of the chunk) cuts every chain's field out of the two masks

@@ -55,17 +55,16 @@ def sweep_bytes(V, k):
     return V * (32 * k + 16)
 
 
-def stored_bytes(V, k, kp, chains_per_wave, potts, lam16, lam_shared):
+def stored_bytes(V, k, kp, chains_per_wave, potts, lam_el, lam_shared):
     """Bytes one sweep launch has to move given how the operands are stored: a lower bound
     for this representation (every array touched once per use, nothing re-read).
       theta       4k per node, read by the row chains and by the column chains
       multipliers one array on one device (read by both sets, written once) or one per set
-                  (each read and written); 2 bytes per entry as int16 counts, else 4
+                  (each read and written); lam_el bytes per entry: 4 as binary32, 2 or 1 as counts
       labels      1 byte: every set reads its own and the crossing chains', writes its own
       back-pointers  Potts step: two 64-bit lane masks per wavefront step (16 B for
                   chains_per_wave nodes), written by the forward pass and read by the
                   trace-back; general step: one byte per padded label per node, likewise"""
-    lam_el = 2 if lam16 else 4
     lam = lam_el * k * (3 if lam_shared else 4)
     labels = 2 * 3
     bp = 2 * 2 * (16.0 / chains_per_wave if potts else kp)
@@ -359,11 +358,12 @@ def main():
         else:
             kp, ns, potts = g.SweepKernelInfo()
             kernel = g.SweepKernelName()
-            lam16 = kernel.endswith("true>")
-            config.update({"kernel": kernel, "potts_step": potts, "lam16": lam16})
+            flags = [f.strip(" >") for f in kernel.split(",")]
+            lam16, lam8 = flags[6] == "true", len(flags) > 8 and flags[8] == "true"
+            config.update({"kernel": kernel, "potts_step": potts, "lam16": lam16, "lam8": lam8})
             b_it = bytes_per_iteration(V, k)
             algo = sweep_bytes(V, k) / world
-            model = stored_bytes(V, k, kp, 64 // (kp * ns), potts, lam16, lam_shared=(nprocs_for_grid == 1)) / world
+            model = stored_bytes(V, k, kp, 64 // (kp * ns), potts, 1 if lam8 else (2 if lam16 else 4), lam_shared=(nprocs_for_grid == 1)) / world
             traffic, traffic_src = measured_traffic(args.workload, world, kernel)
             moved = traffic if traffic else model
             roof = {

@@ -248,9 +248,9 @@ int admm_profile_read(admm_ctx *ctx, double *compute_ms_avg, int *launches);
  * diagnostic without a counterpart in the reference. */
 int admm_sweep_kernel_info(admm_ctx *ctx, int *label_lanes, int *lanes_per_label, int *potts);
 /* The same as the name a kernel trace shows for it, e.g.
- * "chain_sweep_kernel<32, 1, 8, 4, false, true, true>" (labels padded to, lanes
- * per label, prefetch groups, wavefronts per SIMD, dual evaluation, Potts step,
- * int16 multiplier counts), so that a measurement can say which instance it
+ * "chain_sweep_kernel<32, 1, 8, 4, false, true, true, true>" (labels padded to,
+ * lanes per label, prefetch groups, wavefronts per SIMD, dual evaluation, Potts
+ * step, int16 multiplier counts, path compression for the trace-back), so that a measurement can say which instance it
  * timed.  buf receives at most len bytes, NUL-terminated. */
 int admm_sweep_kernel_name(admm_ctx *ctx, char *buf, int len);
 

@@ -224,3 +224,95 @@ def test_single_row_and_single_column():
     for R, C in ((1, 300), (300, 1), (2, 129), (1, 1)):
         k = 32
         _check(R, C, k, _unaries(R, C, k, R + C, quant=2), _potts(k, 0.5), iters=3)
+
+
+@pytest.mark.parametrize("k", [21, 32, 64])
+@pytest.mark.parametrize("shape", [(3, 2), (5, 15), (6, 17), (4, 127), (3, 130), (2, 513), (3, 1023), (2, 1026), (3, 2050), (2300, 3), (40, 33)])
+def test_path_compression_in_the_trace_back(k, shape, monkeypatch):
+    """The Potts kernel that records, per block of eight steps, where every label's path
+    comes from, and traces back block-wise (chosen by itself only for long chains on a busy
+    GPU; ADMM_SWEEP_PCOMP=1 forces it): half chains of 1 to 1150 steps, so partial blocks,
+    partial 64-step chunks, partial rounds and several 512-step pieces all occur; quantised
+    unaries tie in most steps."""
+    monkeypatch.setenv("ADMM_SWEEP_PCOMP", "1")
+    R, C = shape
+    _check(R, C, k, _unaries(R, C, k, 3 * k + R, quant=4), _potts(k, 0.5), G=1, iters=3)
+
+
+@pytest.mark.parametrize("penalty,w", [(0.5, 0.0), (0.3, 0.75), (4.0, float("inf")), (0.5, 1e30)])
+def test_path_compression_with_other_weights_and_penalties(penalty, w, monkeypatch):
+    monkeypatch.setenv("ADMM_SWEEP_PCOMP", "1")
+    for k, (R, C), G in ((32, (70, 300), 3), (64, (33, 140), 2)):
+        _check(R, C, k, _unaries(R, C, k, 17, quant=2), _potts(k, w), G=G, iters=4, penalty=penalty)
+
+
+@pytest.mark.parametrize("G", [1, 3])
+@pytest.mark.parametrize("k", [8, 32, 64])
+def test_int16_counts_on_request(k, G, monkeypatch):
+    """ADMM_LAM8=0: the counts start as int16 (the form they otherwise take once a count nears the int8 range)."""
+    monkeypatch.setenv("ADMM_LAM8", "0")
+    R, C = 70, 150
+    _check(R, C, k, _unaries(R, C, k, 31 + k, quant=4), _potts(k, 0.5), G=G, iters=5)
+
+
+@pytest.mark.parametrize("thr,every", [("1", "1"), ("2", "1"), ("1", "3"), ("2", "2")])
+@pytest.mark.parametrize("G", [1, 3])
+def test_int8_counts_turn_into_int16_in_mid_run(thr, every, G, monkeypatch):
+    """The scan of the int8 counts reports |n| >= 1 or 2 right away, so the arrays change
+    to int16 after a few sweeps, at whatever sweep the host happens to see the report."""
+    monkeypatch.setenv("ADMM_LAM8_THR", thr)
+    monkeypatch.setenv("ADMM_LAM8_EVERY", every)
+    R, C, k = 70, 150, 32
+    _check(R, C, k, _unaries(R, C, k, 79, quant=4), _potts(k, 0.5), G=G, iters=9)
+
+
+@pytest.mark.parametrize("limit", ["2", "5"])
+def test_int8_counts_then_binary32(limit, monkeypatch):
+    """int8 -> (int16 ->) binary32 when the sweep limit of the counts comes first."""
+    monkeypatch.setenv("ADMM_LAM16_LIMIT", limit)
+    monkeypatch.setenv("ADMM_LAM8_THR", "1")
+    monkeypatch.setenv("ADMM_LAM8_EVERY", "4")
+    R, C, k = 40, 90, 16
+    _check(R, C, k, _unaries(R, C, k, 80, quant=4), _potts(k, 0.5), G=2, iters=8)
+
+
+@pytest.mark.parametrize("k,G", [(8, 1), (32, 1), (32, 2)])
+def test_counts_that_outgrow_int8(k, G):
+    """A tiny penalty leaves the two copies of many nodes in disagreement for hundreds of
+    sweeps, so their counts grow by one per sweep and pass 127: with the default scan
+    (threshold 64, every 16 sweeps) the arrays must have become int16 in time.  150
+    iterations against the oracle, multipliers compared as binary32."""
+    from oracle import oracle as O
+    import admm_amd as A
+    R, C = 12, 70
+    pen = 2.0 ** -20
+    un = _unaries(R, C, k, 5, quant=None)
+    W = _potts(k, 0.05)
+    o = O.ChainOracle(R, C, k, un, W, penalty=pen)
+    o.init()
+    gs = []
+    for r in range(G):
+        g = A.Grid(rank=r, nprocs=G)
+        g.SetPartitioner(A.ROW); g.SetPenalties(pen, 1.0); g.SetGlobalInfo(R, C, k); g.Load(un, W); g.InitOptimization()
+        gs.append(g)
+    assert gs[0].SweepKernelName().endswith("true>"), gs[0].SweepKernelName()  # starts on int8 counts
+    for it in range(150):
+        o.compute(); o.update()
+        for g in gs:
+            g.Compute()
+        if G > 1:
+            A.communicate_group(gs)
+        for g in gs:
+            g.Update()
+        if it in (60, 100, 126, 127, 128, 149):
+            lam = np.concatenate([g.State(10).reshape(-1, C, k) for g in gs], axis=0)
+            assert np.array_equal(lam, o.lambda_row), "row multipliers after %d sweeps" % (it + 1)
+            lab = np.concatenate([g.Labels().reshape(-1, C) for g in gs], axis=0)
+            assert np.array_equal(lab, o.labels()), "labels after %d sweeps" % (it + 1)
+    n = np.abs(o.lambda_row / np.float32(pen / 2)).max()
+    assert n > 127, "the case does not leave the int8 range (max count %d)" % n
+    assert not gs[0].SweepKernelName().endswith("true>"), "still on int8 counts"
+    lamc = np.concatenate([g.State(11).reshape(R, -1, k) for g in gs], axis=1)
+    assert np.array_equal(lamc, o.lambda_col)
+    for g in gs:
+        g.close()
