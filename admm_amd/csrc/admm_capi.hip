@@ -341,6 +341,24 @@ void launch_sweep_t(const ChainArgs &a, int blocks, hipStream_t s) {
   hipLaunchKernelGGL((chain_sweep_kernel<KP, NS, sweep_gpb(KP, NS), sweep_minw(KP, NS), DUAL>), dim3(blocks), dim3(kChainBlock), 0, s, a);
 }
 
+// Two wavefronts per half chain (the kernels built with SPLIT): for launches that leave
+// half of the SIMDs without a wavefront (one strip of eight of the 2048 x 2048 grid: 512
+// wavefronts; 0.189 -> 0.178 ms per sweep).  With a wavefront on every SIMD already (one
+// strip of four) the second one only competes: 0.195 -> 0.224 ms.  The gain is small because
+// a lone wavefront's step is bound by the recursion's own dependent instructions, which the
+// shell's used to fill the gaps of.  ADMM_SWEEP_TWOWAVE=0/1 (tuning and test knob) overrides.
+bool twowave_chosen(int KP, int waves) {
+  if (KP != 32) return false;
+  if (const char *e = getenv("ADMM_SWEEP_TWOWAVE")) return atoi(e) != 0;
+  return waves <= 512;
+}
+template <int KP>
+void launch_sweep_potts_split_t(const ChainArgs &a, int blocks, hipStream_t s, bool lam16, bool lam8) {
+  if (lam8) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, false, true, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+  else if (lam16) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, false, false, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+  else hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, false, false, false, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+}
+
 template <int KP, bool PCOMP = false>
 void launch_sweep_potts_t(const ChainArgs &a, int blocks, hipStream_t s) {
   // a step needs few registers: four wavefronts per SIMD, operands fetched 8 steps ahead
@@ -410,6 +428,12 @@ int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
     }
   }
   hipStream_t s = c->stream;
+  if (potts && twowave_chosen(sh.KP, w)) {
+    a.mix_blocks = 0;
+    launch_sweep_potts_split_t<32>(a, w / 2, s, c->lam16, c->lam16 && c->lam8);  // a workgroup per group of chains
+    HIP_TRY(c, hipGetLastError());
+    return ADMM_OK;
+  }
   const bool pcomp = potts && pcomp_chosen(sh.KP, w);
   if (potts && c->lam16) {
     switch (sh.KP) {
@@ -2408,10 +2432,11 @@ int admm_sweep_kernel_name(admm_ctx *c, char *buf, int len) {
     // the same count of wavefronts launch_sweep works out
     const int CPW = 64 / sh.KP;
     const int waves = 2 * ((c->d.batch * c->st.nrows + CPW - 1) / CPW) + 2 * ((c->d.batch * c->st.ncols + CPW - 1) / CPW);
-    snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, 1, 8, 4, false, true, %s, %s, %s>", sh.KP, c->lam16 ? "true" : "false",
-             pcomp_chosen(sh.KP, waves) ? "true" : "false", (c->lam16 && c->lam8) ? "true" : "false");
+    const bool two = twowave_chosen(sh.KP, waves);
+    snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, 1, 8, 4, false, true, %s, %s, %s, %s>", sh.KP, c->lam16 ? "true" : "false",
+             (!two && pcomp_chosen(sh.KP, waves)) ? "true" : "false", (c->lam16 && c->lam8) ? "true" : "false", two ? "true" : "false");
   } else
-    snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, %d, %d, %d, false, false, false, false, false>", sh.KP, sh.NS, sweep_gpb(sh.KP, sh.NS), sweep_minw(sh.KP, sh.NS));
+    snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, %d, %d, %d, false, false, false, false, false, false>", sh.KP, sh.NS, sweep_gpb(sh.KP, sh.NS), sweep_minw(sh.KP, sh.NS));
   return ADMM_OK;
 }
 

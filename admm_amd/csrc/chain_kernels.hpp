@@ -252,6 +252,12 @@ constexpr unsigned long long kFieldLsb = W >= 64 ? 1ull : (~0ull / ((1ull << (W 
 // MINW : wavefronts per SIMD the register allocation must leave room for
 // DUAL : evaluate the chain minimum under theta + lambda only (no dual
 //        update, no back-pointers, no labels)
+// SPLIT: two wavefronts per half chain.  One (the shell) loads the operands, does the dual
+//        update and the potential adjust, stores the multipliers and sums the unary term of
+//        the objective; the other (the recursion) takes the adjusted unaries from a ring in
+//        LDS and does the min-plus step, the back-pointers and the trace-back.  A wavefront
+//        that has its SIMD to itself is bound by the instructions it issues, so halving a
+//        step's instructions per wavefront is what speeds a launch with few chains up.
 // PCOMP: Potts step with path compression for the trace-back (see there)
 // LAM8 : with LAM16, the counts are int8: the host runs these kernels while it knows
 //        every count to be far from +-127 (it scans the arrays every few sweeps)
@@ -267,10 +273,11 @@ constexpr unsigned long long kFieldLsb = W >= 64 ? 1ull : (~0ull / ((1ull << (W 
 // straight from registers, dword (t/4)*KP + b of the half chain's scratch;
 // the backtrack streams them back one 64-step chunk at a time (t counts the
 // steps of the half chain in sweep order).
-template <int KP, int NS, int GPB, int MINW, bool DUAL, bool POTTS = false, bool LAM16 = false, bool PCOMP = false, bool LAM8 = false>
+template <int KP, int NS, int GPB, int MINW, bool DUAL, bool POTTS = false, bool LAM16 = false, bool PCOMP = false, bool LAM8 = false, bool SPLIT = false>
 __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const ChainArgs args) {
   static_assert(!PCOMP || POTTS, "path compression belongs to the Potts step");
   static_assert(!LAM8 || LAM16, "LAM8: the counts of LAM16, one byte each");
+  static_assert(!SPLIT || !DUAL, "the dual evaluation is never split over two wavefronts");
   typedef typename std::conditional<LAM8, int8_t, int16_t>::type count_t;
   constexpr unsigned CB = sizeof(count_t);  // bytes per count
   static_assert(!POTTS || (NS == 1 && !DUAL), "the Potts step keeps a label's message in its one lane");
@@ -318,13 +325,21 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   static_assert(!PCOMP || TB_W >= CPW * TB_RSTEPS, "the round's labels reuse the record staging");
   __shared__ __attribute__((aligned(16))) uint32_t s_tb[WPB][PCOMP ? TB_W : 4];
 
+  // SPLIT: adjusted unaries on their way from the shell to the recursion wavefront, three
+  // blocks of GPB load groups per half chain (written, waiting, being read)
+  __shared__ float s_ring[SPLIT ? 2 : 1][SPLIT ? 3 * GPB : 1][64];
+
   const int lane = threadIdx.x & 63;
   // the wavefront index is the same in all 64 lanes: keep it (and what
   // derives from it) in scalar registers
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int wave = blockIdx.x * WPB + wib;
+  // SPLIT: a workgroup holds the two halves of one group of chains, two wavefronts each
+  // (role 0: recursion, role 1: shell); the host fills workgroups set after set
+  const int role = SPLIT ? (wib & 1) : 0;
+  if constexpr (SPLIT) wave = blockIdx.x * 2 + (wib >> 1);
   int si;
-  if (args.mix_blocks > 0) {
+  if (!SPLIT && args.mix_blocks > 0) {
     static_assert(WPB == 4, "a workgroup is two pairs of wavefronts");
     const int blk = blockIdx.x;
     int wl;
@@ -353,7 +368,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // waves 2p, 2p+1 of a segment: left and right half of the chains of group p
   const int wlocal = wave - args.wave_begin[si];
   const int rev = wlocal & 1;   // 1: the right half, swept from the chain's last node backwards
-  const int pair = wib >> 1;    // wave_begin is even, so the two halves sit in one workgroup
+  const int pair = SPLIT ? 0 : wib >> 1;  // wave_begin is even, so the two halves sit in one workgroup
   const int chain_raw = (wlocal >> 1) * CPW + cs;
   const bool cvalid = chain_raw < sg.nchains;
   const int chain = cvalid ? chain_raw : sg.nchains - 1;
@@ -516,11 +531,11 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
 #pragma unroll
   for (int j = 0; j < GPB; j++) {
     const unsigned soff = soff0 + (unsigned)(j * NS) * sstep;
-    pth[j] = buf_load(th_rs, soff);
-    plam[j] = lam_load((unsigned)(j * NS));
+    pth[j] = (!SPLIT || role == 1) ? buf_load(th_rs, soff) : 0.0f;
+    plam[j] = (!SPLIT || role == 1) ? lam_load((unsigned)(j * NS)) : 0.0f;
   }
   int xnext = -1, xonext = -1;  // labels of the next 64-step chunk, in flight
-  if (!DUAL) {
+  if (!DUAL && (!SPLIT || role == 1)) {
     for (int i = within; i < kChunk; i += LPC) {
       s_x[wib][cs][i] = (i < T) ? xchain[xdir * i] : -1;
       s_xo[wib][cs][i] = (i < T) ? xochain[xdir * i] : -1;
@@ -663,14 +678,19 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // The order inside a step is pinned with scheduling barriers: LDS reads
   // first, then the previous step's arg-min (it covers the LDS latency), then
   // the min-plus of this step.
-  auto block = [&](const int tb, const int tt0, auto full_tag) {
+  // role_tag: 0 the whole step; SPLIT: 1 the shell's part (slot: the ring's block it fills),
+  // 2 the recursion's part (thr: the block's adjusted unaries, fetched from the ring a block ago)
+  float thr[SPLIT ? GPB : 1];
+  auto block = [&](const int tb, const int tt0, auto full_tag, auto role_tag, const int slot) {
     constexpr bool FULL = decltype(full_tag)::value;
-    if constexpr (PCOMP) {
+    constexpr int ROLE = decltype(role_tag)::value;
+    constexpr bool SHELL = ROLE != 2, REC = ROLE != 1;
+    if constexpr (PCOMP && REC) {
       static_assert(!PCOMP || BLK == 8, "the trace-back's records are one per unrolled block of eight steps");
       origin_block(tb);
     }
     int xown = -1, xoth = -1;  // labels of the current group (own step of this lane)
-    if (!DUAL) {
+    if (!DUAL && SHELL) {
       xown = s_x[wib][cs][tt0 + s];
       xoth = s_xo[wib][cs][tt0 + s];
     }
@@ -678,7 +698,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     constexpr bool PAIRED = POTTS && LAM16 && GPB % 2 == 0;
     int xown1 = -1, xoth1 = -1;  // labels of the step after the current one
     float th_pair = INF;         // adjusted unary of the odd step, worked out with the even one
-    if constexpr (PAIRED) {
+    if constexpr (PAIRED && SHELL) {
       xown1 = s_x[wib][cs][tt0 + 1];
       xoth1 = s_xo[wib][cs][tt0 + 1];
     }
@@ -686,12 +706,14 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       constexpr int j = decltype(j_c)::value;
       const int tg = tb + j * NS;
       const bool glive = FULL || tg < T;
-      const float th_in = pth[j];
-      const int n_in = __float_as_int(plam[j]);  // LAM16: the count
-      const float lam_in = LAM16 ? (float)n_in * shpen : __uint_as_float(__float_as_uint(plam[j]) ^ lam_sign);
+      const float th_in = pth[SHELL ? j : 0];
+      const int n_in = __float_as_int(plam[SHELL ? j : 0]);  // LAM16: the count
+      const float lam_in = LAM16 ? (float)n_in * shpen : __uint_as_float(__float_as_uint(plam[SHELL ? j : 0]) ^ lam_sign);
       const unsigned goff = soff0 + (unsigned)tg * sstep;  // uniform
       float th_own = INF;
-      if constexpr (PAIRED) {
+      if constexpr (!SHELL) {
+        th_own = thr[SPLIT ? j : 0];
+      } else if constexpr (PAIRED) {
         // The shell is elementwise, so steps j and j + 1 go through it together on
         // packed binary32 instructions.  With d = [x_own = b] - [x_other = b] and
         // m = +-n + d (the set's sign on the count):
@@ -748,6 +770,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         }
         th_own = rho * (th_in + la) + p;                      // Tree.cpp:85-86
       }
+      if constexpr (ROLE == 1) s_ring[rev][slot * GPB + j][lane] = th_own;
       static_for<0, NS>([&](auto u_c) {
         constexpr int u = decltype(u_c)::value;
         const bool live = FULL || tg + u < T;
@@ -756,7 +779,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         // (a) this step's messages leave LDS, with the next group's labels
         //     and the operands of the group one block ahead behind them ...
         f4 mv[(A + 3) / 4];
-        if (live && !POTTS) {
+        if (live && !POTTS && REC) {
           if constexpr (A % 4 == 0) {
             const f4 *mp = reinterpret_cast<const f4 *>(Mrow + (RECOMP ? ((j * NS + u) & 1) * MROW : 0) + s * A);
 #pragma unroll
@@ -766,7 +789,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
             for (int q = 0; q < A; q++) mv[q / 4][q % 4] = Mrow[s * A + q];
           }
         }
-        if (u == NS - 1) {
+        if (u == NS - 1 && SHELL) {
           if constexpr (PAIRED) {
             if (j % 2 == 1 && j + 1 < GPB) {
               xown = s_x[wib][cs][tt0 + j + 1];
@@ -788,7 +811,8 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         else if constexpr (NS > 1) __builtin_amdgcn_sched_barrier(0x6);
         else __builtin_amdgcn_sched_barrier(0);
         // (b) ... while the previous step's back-pointer is worked out
-        if constexpr (RECOMP) {
+        if constexpr (!REC) {
+        } else if constexpr (RECOMP) {
           // compare for the step two back, then locate for the step one back
           constexpr int P = j * NS + u;
           constexpr int Q2 = (P + BLK - 2) % BLK, Q1 = (P + BLK - 1) % BLK;
@@ -806,7 +830,8 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
           __builtin_amdgcn_sched_barrier(0);
         }
         // (c) min-plus of this step
-        if constexpr (POTTS) {
+        if constexpr (!REC) {
+        } else if constexpr (POTTS) {
           if (live) {
             const float c = Mreg + wpot;
             const float C1 = chain_lanes_min<KP>(c);
@@ -885,7 +910,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
           s_M[wib][(RECOMP ? (((j * NS + u) & 1) ^ 1) * MROW : 0) + m_addr[u]] = Mnew;
           wave_lds_fence();
         }
-        if constexpr (!PIPE && !POTTS) finish(std::integral_constant<int, j * NS + u>{}, tb, live);
+        if constexpr (!PIPE && !POTTS && REC) finish(std::integral_constant<int, j * NS + u>{}, tb, live);
       });
     });
   };
@@ -905,6 +930,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       default: __builtin_amdgcn_s_setprio(3); break;
     }
   };
+  if constexpr (!SPLIT) {
   for (int t0 = 0; t0 < T; t0 += kChunk) {
     set_prio(prio_slot + t0 / kChunk);
     if (!DUAL) {
@@ -917,10 +943,10 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     }
     if (t0 + kChunk <= T) {
 #pragma unroll 2
-      for (int tt = 0; tt < kChunk; tt += BLK) block(t0 + tt, tt, std::true_type{});
+      for (int tt = 0; tt < kChunk; tt += BLK) block(t0 + tt, tt, std::true_type{}, std::integral_constant<int, 0>{}, 0);
     } else {
 #pragma unroll 1
-      for (int tt = 0; tt < kChunk && t0 + tt < T; tt += BLK) block(t0 + tt, tt, std::false_type{});  // tail
+      for (int tt = 0; tt < kChunk && t0 + tt < T; tt += BLK) block(t0 + tt, tt, std::false_type{}, std::integral_constant<int, 0>{}, 0);  // tail
     }
     if constexpr (POTTS) {
       uint32_t *o = bpwave + (t0 / kChunk) * 256 + lane;
@@ -939,6 +965,76 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         }
       }
       wave_lds_fence();
+    }
+  }
+
+  } else {
+    // Two wavefronts per half chain.  In round ib the shell works on block ib and the
+    // recursion on block ib - 2 with the adjusted unaries it fetched from the ring in
+    // round ib - 1; a workgroup barrier ends every round.  All four wavefronts of the
+    // workgroup run the same number of rounds (the longer half's).
+    const int nblk = (Lhalf + BLK - 1) / BLK;
+    typedef std::integral_constant<int, 1> shell_t;
+    typedef std::integral_constant<int, 2> rec_t;
+    for (int ib = 0; ib < nblk + 2; ib++) {
+      if (role == 1) {
+        const int tb = ib * BLK, tt = tb & (kChunk - 1);
+        if (tb < T) {
+          if (tt == 0 && LPC >= kChunk) {
+            // labels of this chunk are in LDS; fetch the next chunk's while this one runs
+            const bool ok = tb + kChunk + within < T;
+            xnext = ok ? xchain[xdir * (tb + kChunk + within)] : -1;
+            xonext = ok ? xochain[xdir * (tb + kChunk + within)] : -1;
+          }
+          if (tb + BLK <= T) block(tb, tt, std::true_type{}, shell_t{}, ib % 3);
+          else block(tb, tt, std::false_type{}, shell_t{}, ib % 3);
+          if (tt + BLK == kChunk && tb + BLK < T) {
+            const int t0 = tb - tt;
+            wave_lds_fence();
+            if (LPC >= kChunk) {
+              s_x[wib][cs][within] = xnext;
+              s_xo[wib][cs][within] = xonext;
+            } else {
+              for (int i = within; i < kChunk; i += LPC) {
+                const bool ok = t0 + kChunk + i < T;
+                s_x[wib][cs][i] = ok ? xchain[xdir * (t0 + kChunk + i)] : -1;
+                s_xo[wib][cs][i] = ok ? xochain[xdir * (t0 + kChunk + i)] : -1;
+              }
+            }
+            wave_lds_fence();
+          }
+        }
+      } else {
+        if (ib >= 2) {
+          const int tb = (ib - 2) * BLK, tt = tb & (kChunk - 1);
+          if (tb < T) {
+            if (tb + BLK <= T) block(tb, tt, std::true_type{}, rec_t{}, 0);
+            else block(tb, tt, std::false_type{}, rec_t{}, 0);
+            if constexpr (POTTS) {
+              if (tt + BLK == kChunk || tb + BLK >= T) {
+                uint32_t *o = bpwave + (tb / kChunk) * 256 + lane;
+                o[0] = (uint32_t)vk0; o[64] = (uint32_t)vk1; o[128] = (uint32_t)ve0; o[192] = (uint32_t)ve1;
+              }
+            }
+          }
+        }
+        if (ib >= 1 && (ib - 1) * BLK < T) {
+          // the block the shell finished a round ago, for the next round
+#pragma unroll
+          for (int j = 0; j < GPB; j++) thr[SPLIT ? j : 0] = s_ring[rev][((ib - 1) % 3) * GPB + j][lane];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    if (role == 1) {
+      // the shell's share of the results: the unary term of the objective; then it is done
+      // (the barriers of the join do not wait for wavefronts that have ended)
+#pragma unroll
+      for (int d = 1; d < LPC; d <<= 1) unary_acc += __shfl_xor(unary_acc, d);
+      if (cvalid && within == 0) sg.chain_unary[2 * chain + rev] = unary_acc;
+      return;
     }
   }
 
@@ -1029,9 +1125,11 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     return;
   }
 
+  if constexpr (!SPLIT) {
 #pragma unroll
-  for (int d = 1; d < LPC; d <<= 1) unary_acc += __shfl_xor(unary_acc, d);
-  if (cvalid && within == 0) sg.chain_unary[2 * chain + rev] = unary_acc;
+    for (int d = 1; d < LPC; d <<= 1) unary_acc += __shfl_xor(unary_acc, d);
+    if (cvalid && within == 0) sg.chain_unary[2 * chain + rev] = unary_acc;
+  }
   if (T == 0) {  // right half of a one-node chain: nothing to trace
     if (cvalid && within == 0) sg.chain_lin[2 * chain + rev] = 0.0;
     return;

@@ -235,6 +235,7 @@ def test_path_compression_in_the_trace_back(k, shape, monkeypatch):
     partial 64-step chunks, partial rounds and several 512-step pieces all occur; quantised
     unaries tie in most steps."""
     monkeypatch.setenv("ADMM_SWEEP_PCOMP", "1")
+    monkeypatch.setenv("ADMM_SWEEP_TWOWAVE", "0")
     R, C = shape
     _check(R, C, k, _unaries(R, C, k, 3 * k + R, quant=4), _potts(k, 0.5), G=1, iters=3)
 
@@ -242,6 +243,7 @@ def test_path_compression_in_the_trace_back(k, shape, monkeypatch):
 @pytest.mark.parametrize("penalty,w", [(0.5, 0.0), (0.3, 0.75), (4.0, float("inf")), (0.5, 1e30)])
 def test_path_compression_with_other_weights_and_penalties(penalty, w, monkeypatch):
     monkeypatch.setenv("ADMM_SWEEP_PCOMP", "1")
+    monkeypatch.setenv("ADMM_SWEEP_TWOWAVE", "0")
     for k, (R, C), G in ((32, (70, 300), 3), (64, (33, 140), 2)):
         _check(R, C, k, _unaries(R, C, k, 17, quant=2), _potts(k, w), G=G, iters=4, penalty=penalty)
 
@@ -295,7 +297,8 @@ def test_counts_that_outgrow_int8(k, G):
         g = A.Grid(rank=r, nprocs=G)
         g.SetPartitioner(A.ROW); g.SetPenalties(pen, 1.0); g.SetGlobalInfo(R, C, k); g.Load(un, W); g.InitOptimization()
         gs.append(g)
-    assert gs[0].SweepKernelName().endswith("true>"), gs[0].SweepKernelName()  # starts on int8 counts
+    on_int8 = lambda g: g.SweepKernelName().split(",")[8].strip(" >") == "true"
+    assert on_int8(gs[0]), gs[0].SweepKernelName()  # starts on int8 counts
     for it in range(150):
         o.compute(); o.update()
         for g in gs:
@@ -311,8 +314,27 @@ def test_counts_that_outgrow_int8(k, G):
             assert np.array_equal(lab, o.labels()), "labels after %d sweeps" % (it + 1)
     n = np.abs(o.lambda_row / np.float32(pen / 2)).max()
     assert n > 127, "the case does not leave the int8 range (max count %d)" % n
-    assert not gs[0].SweepKernelName().endswith("true>"), "still on int8 counts"
+    assert not on_int8(gs[0]), "still on int8 counts"
     lamc = np.concatenate([g.State(11).reshape(R, -1, k) for g in gs], axis=1)
     assert np.array_equal(lamc, o.lambda_col)
     for g in gs:
         g.close()
+
+
+@pytest.mark.parametrize("two", ["0", "1"])
+@pytest.mark.parametrize("penalty,w", [(0.5, 0.5), (0.3, 0.75), (4.0, float("inf")), (0.5, 0.0)])
+@pytest.mark.parametrize("shape,G", [((150, 262), 1), ((150, 262), 3), ((3, 2), 1), ((1, 77), 1), ((70, 1), 1), ((5, 1030), 1), ((2050, 3), 2)])
+def test_one_and_two_wavefronts_per_half_chain(two, penalty, w, shape, G, monkeypatch):
+    """32 labels have a kernel that gives every half chain two wavefronts (one for the ADMM
+    shell, one for the recursion; chosen by itself when chains are scarce) next to the one
+    that gives it one: both forced here, on binary32 multipliers and on counts, whole and
+    partial blocks, chunks and chains of one node."""
+    monkeypatch.setenv("ADMM_SWEEP_TWOWAVE", two)
+    R, C = shape
+    _check(R, C, 32, _unaries(R, C, 32, 41 + R, quant=4), _potts(32, w), G=G, iters=4, penalty=penalty)
+
+
+def test_two_wavefronts_with_int16_counts_and_21_labels(monkeypatch):
+    monkeypatch.setenv("ADMM_SWEEP_TWOWAVE", "1")
+    monkeypatch.setenv("ADMM_LAM8", "0")
+    _check(90, 200, 21, _unaries(90, 200, 21, 9, quant=4), _potts(21, 0.5), G=2, iters=5)
