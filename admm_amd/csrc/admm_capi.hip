@@ -151,6 +151,9 @@ struct admm_ctx {
   // the table the sweep runs on (Wt) has a zero diagonal and one non-negative
   // value everywhere else: the sweep kernel specialised for that form applies
   bool potts = false;
+  // ... or is a function g(|a - b|) of the label distance that is constant from distance 4 on and
+  // nowhere above that constant (truncated linear / quadratic ...): the sweep specialised for it
+  bool trunc3 = false;
   float *d_chain_min = nullptr;
   // The linear objective of a solve has two per-chain terms: the pairwise one
   // is written by that solve's sweep, the unary one by the NEXT sweep (which
@@ -397,15 +400,17 @@ bool potts_enabled() {
 // 8 labels or more: the Potts kernel (with four or more chains per wavefront its trace-back
 // runs one lane per chain, otherwise on the scalar unit).  2 or 4 labels: the general
 // kernel's scan is as short.
-bool potts_chosen(const admm_ctx *c, SweepShape sh) {
-  if (c->lam16) return true;  // the arrays are in the form only that kernel reads
-  return c->potts && sh.KP >= 8 && potts_enabled();
-}
+bool potts_chosen(const admm_ctx *c, SweepShape sh) { return c->potts && sh.KP >= 8 && potts_enabled(); }
+
+// The step specialised for truncated tables: 16 label lanes, and only where the Potts kernel
+// (which is the same idea with no neighbours) does not apply.
+bool trunc_chosen(const admm_ctx *c, SweepShape sh) { return c->trunc3 && sh.KP == 16 && !potts_chosen(c, sh); }
 
 template <bool DUAL>
 int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
   const bool potts = !DUAL && potts_chosen(c, sh);
-  if (potts) sh.NS = 1;  // a label's message stays in its one lane
+  const bool trunc = !DUAL && trunc_chosen(c, sh);
+  if (potts || trunc) sh.NS = 1;  // a label's message stays in its one lane
   const int CPW = 64 / (sh.KP * sh.NS);
   int w = 0;
   for (int i = 0; i < a.nseg; i++) {
@@ -456,6 +461,12 @@ int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
     }
     HIP_TRY(c, hipGetLastError());
     return ADMM_OK;
+  }
+  if (trunc) {
+    if (c->lam16 && c->lam8) hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, true, false, true, false, 3>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+    else if (c->lam16) hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, true, false, false, false, 3>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+    else hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, false, false, false, false, 3>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+    goto launched;
   }
 #define SWEEP_CASE(kp, ns) \
   if (sh.KP == kp && sh.NS == ns) { launch_sweep_t<kp, ns, DUAL>(a, blocks, s); goto launched; }
@@ -1467,15 +1478,35 @@ int admm_init(admm_ctx *c) {
     for (int a = 0; a < d.k && potts; a++)
       for (int b = 0; b < d.k && potts; b++) potts = (a == b) ? wt[(size_t)a * d.k + b] == 0.0f : wt[(size_t)a * d.k + b] == wt[1];
     c->potts = potts;
-    // int16 multiplier counts (the LAM16 kernels): the Potts kernel,
-    // penalty / 2 a power of two well inside the binary32 range.
+    {
+      // W[a][b] = g[|a - b|], g constant beyond distance 3 and nowhere above that constant
+      const int k = d.k;
+      bool tr = true;
+      for (int a = 0; a < k && tr; a++)
+        for (int b = 0; b < k && tr; b++) tr = wt[(size_t)a * k + b] == wt[(size_t)std::abs(a - b)];
+      const float wfar = k > 4 ? wt[4] : INFINITY;
+      for (int dd = 5; dd < k && tr; dd++) tr = wt[(size_t)dd] == wfar;
+      for (int dd = 0; dd < std::min(k, 4) && tr; dd++) tr = wt[(size_t)dd] <= wfar;
+      // Four chains share a wavefront in that kernel: it takes about half the instructions
+      // per chain and step of the general one, which spreads a chain over a whole wavefront,
+      // but on a quarter of the wavefronts.  While those leave SIMDs empty the general kernel
+      // is the faster one (512 x 512: 512 wavefronts, 0.061 against 0.053 ms per sweep;
+      // 1024 x 1024: 1024 wavefronts, 0.114 against 0.185 ms).
+      // ADMM_SWEEP_TRUNC=0/1 (tuning and test knob) overrides the choice.
+      const long long tw = 2 * (((long long)d.batch * c->st.nrows + 3) / 4) + 2 * (((long long)d.batch * c->st.ncols + 3) / 4);
+      const char *et = getenv("ADMM_SWEEP_TRUNC");
+      c->trunc3 = tr && c->KP == 16 && (et ? atoi(et) != 0 : tw >= 640);
+    }
+    // int16 multiplier counts (the LAM16 kernels): the Potts kernel or the one for truncated
+    // tables (the general kernel reads binary32 only), penalty / 2 a power of two well inside
+    // the binary32 range.
     // ADMM_LAM16=0 keeps binary32; ADMM_LAM16_LIMIT=n switches to it after n sweeps (test knobs).
     {
       const float hpen = d.penalty * 0.5f;
       int ex = 0;
       const bool pow2 = hpen > 0.0f && std::frexp(hpen, &ex) == 0.5f && ex > -100 && ex < 100;
       const char *e16 = getenv("ADMM_LAM16"), *elim = getenv("ADMM_LAM16_LIMIT");
-      c->lam16 = potts && c->KP >= 8 && potts_enabled() && pow2 && !(e16 && atoi(e16) == 0);
+      c->lam16 = ((potts && c->KP >= 8 && potts_enabled()) || c->trunc3) && pow2 && !(e16 && atoi(e16) == 0);
       c->lam16_sweeps = 0;
       c->lam16_limit = elim ? std::max(0, std::min(32000, atoi(elim))) : 32000;
       // int8 counts: ADMM_LAM8=0 never; ADMM_LAM8_THR / ADMM_LAM8_EVERY move the scan's threshold and
@@ -2413,7 +2444,7 @@ int admm_sweep_kernel_info(admm_ctx *c, int *label_lanes, int *lanes_per_label, 
   if (!c->inited) return fail(c, ADMM_E_STATE, "admm_sweep_kernel_info before admm_init");
   SweepShape sh = pick_shape(c->KP, (long long)c->d.batch * ((long long)c->st.nrows + c->st.ncols));
   const bool potts = potts_chosen(c, sh);
-  if (potts) sh.NS = 1;
+  if (potts || trunc_chosen(c, sh)) sh.NS = 1;
   if (label_lanes) *label_lanes = sh.KP;
   if (lanes_per_label) *lanes_per_label = sh.NS;
   if (potts_out) *potts_out = potts ? 1 : 0;
@@ -2433,10 +2464,13 @@ int admm_sweep_kernel_name(admm_ctx *c, char *buf, int len) {
     const int CPW = 64 / sh.KP;
     const int waves = 2 * ((c->d.batch * c->st.nrows + CPW - 1) / CPW) + 2 * ((c->d.batch * c->st.ncols + CPW - 1) / CPW);
     const bool two = twowave_chosen(sh.KP, waves);
-    snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, 1, 8, 4, false, true, %s, %s, %s, %s>", sh.KP, c->lam16 ? "true" : "false",
+    snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, 1, 8, 4, false, true, %s, %s, %s, %s, 0>", sh.KP, c->lam16 ? "true" : "false",
              (!two && pcomp_chosen(sh.KP, waves)) ? "true" : "false", (c->lam16 && c->lam8) ? "true" : "false", two ? "true" : "false");
-  } else
-    snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, %d, %d, %d, false, false, false, false, false, false>", sh.KP, sh.NS, sweep_gpb(sh.KP, sh.NS), sweep_minw(sh.KP, sh.NS));
+  } else if (trunc_chosen(c, sh))
+    snprintf(buf, (size_t)len, "chain_sweep_kernel<16, 1, 8, 4, false, false, %s, false, %s, false, 3>", c->lam16 ? "true" : "false",
+             (c->lam16 && c->lam8) ? "true" : "false");
+  else
+    snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, %d, %d, %d, false, false, false, false, false, false, 0>", sh.KP, sh.NS, sweep_gpb(sh.KP, sh.NS), sweep_minw(sh.KP, sh.NS));
   return ADMM_OK;
 }
 

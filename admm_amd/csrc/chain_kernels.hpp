@@ -252,6 +252,10 @@ constexpr unsigned long long kFieldLsb = W >= 64 ? 1ull : (~0ull / ((1ull << (W 
 // MINW : wavefronts per SIMD the register allocation must leave room for
 // DUAL : evaluate the chain minimum under theta + lambda only (no dual
 //        update, no back-pointers, no labels)
+// TRUNC: n > 0: the step specialised for tables W[a][b] = g(|a - b|) with g constant from
+//        distance n + 1 on and nowhere above that constant (truncated linear, truncated
+//        quadratic, Potts ...): the 2n + 1 nearest sources through DPP row shifts of the
+//        register-resident messages plus one chain-wide minimum, see there
 // SPLIT: two wavefronts per half chain.  One (the shell) loads the operands, does the dual
 //        update and the potential adjust, stores the multipliers and sums the unary term of
 //        the objective; the other (the recursion) takes the adjusted unaries from a ring in
@@ -273,17 +277,23 @@ constexpr unsigned long long kFieldLsb = W >= 64 ? 1ull : (~0ull / ((1ull << (W 
 // straight from registers, dword (t/4)*KP + b of the half chain's scratch;
 // the backtrack streams them back one 64-step chunk at a time (t counts the
 // steps of the half chain in sweep order).
-template <int KP, int NS, int GPB, int MINW, bool DUAL, bool POTTS = false, bool LAM16 = false, bool PCOMP = false, bool LAM8 = false, bool SPLIT = false>
+template <int KP, int NS, int GPB, int MINW, bool DUAL, bool POTTS = false, bool LAM16 = false, bool PCOMP = false, bool LAM8 = false, bool SPLIT = false, int TRUNC = 0>
 __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const ChainArgs args) {
   static_assert(!PCOMP || POTTS, "path compression belongs to the Potts step");
   static_assert(!LAM8 || LAM16, "LAM8: the counts of LAM16, one byte each");
   static_assert(!SPLIT || !DUAL, "the dual evaluation is never split over two wavefronts");
+  static_assert(TRUNC == 0 || (!POTTS && !DUAL && NS == 1 && KP <= 16 && TRUNC <= 7),
+                "the truncated step shifts messages inside a row of sixteen lanes");
   typedef typename std::conditional<LAM8, int8_t, int16_t>::type count_t;
   constexpr unsigned CB = sizeof(count_t);  // bytes per count
   static_assert(!POTTS || (NS == 1 && !DUAL), "the Potts step keeps a label's message in its one lane");
   static_assert(!LAM16 || (NS == 1 && !DUAL), "int16 multipliers: one step per load group, never the dual evaluation");
   constexpr int LPC = KP * NS;   // lanes per chain
   constexpr int CPW = 64 / LPC;  // chains per wavefront
+  // trace-back on the scalar unit with the back-pointers in registers (see there; with four
+  // chains the walk through LDS, one lane per chain, is the faster one: 29 k against 37 k clock
+  // ticks for 256 steps)
+  constexpr bool SWALK = CPW <= 2;
   constexpr int A = KP / NS;     // source labels scanned per lane
   constexpr int BLK = GPB * NS;  // steps per unrolled block
   constexpr int WIN = 4 * NS;    // steps per back-pointer store (one dword per lane)
@@ -299,11 +309,11 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // messages of a step must then outlive the step: two alternating rows.
   // (tried for the split k = 32 kernel too, 16 candidates per lane: slower, its
   // single wavefront per SIMD feels the extra LDS traffic)
-  constexpr bool RECOMP = !POTTS && !DUAL && NS == 1 && A >= 32;
+  constexpr bool RECOMP = !POTTS && !DUAL && NS == 1 && A >= 32 && TRUNC == 0;
   constexpr int NG = A / 4;      // candidate groups per lane
   constexpr int NB = RECOMP ? 2 : 1;
   constexpr int WLD = KP + 4;    // padded row of the LDS pairwise table
-  constexpr bool PIPE = !POTTS && (RECOMP || A <= 32);
+  constexpr bool PIPE = !POTTS && TRUNC == 0 && (RECOMP || A <= 32);
   constexpr int WPB = kChainBlock / 64;
   constexpr int MROW = CPW * KP + 64;
 
@@ -311,8 +321,8 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   __shared__ __attribute__((aligned(16))) float s_W[2][RECOMP ? KP * WLD : 4];  // per direction: [target][source]
   __shared__ float s_join[WPB / 2][CPW * KP];  // last message of the left halves
   __shared__ int s_joinx[WPB / 2][CPW];        // label of the left halves' last node, from the join
-  __shared__ int s_x[WPB][CPW][kChunk];
-  __shared__ int s_xo[WPB][CPW][kChunk];
+  __shared__ __attribute__((aligned(16))) int s_x[WPB][CPW][kChunk];
+  __shared__ __attribute__((aligned(16))) int s_xo[WPB][CPW][kChunk];
   __shared__ __attribute__((aligned(16))) uint32_t s_bp[WPB][CPW][PCOMP ? 1 : 16 * KP];
   // Trace-back of the Potts step (see there): a round's step records, transposed so that one
   // lane per block of eight steps reads its block's, then the round's labels
@@ -393,8 +403,8 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // pairwise column of this lane's target label, kept in registers; the
   // right half runs on the transposed table (source = label of the later node)
   const float *__restrict__ Wuse = rev ? args.WtT : args.Wt;
-  float Wr[POTTS ? 1 : A];
-  if constexpr (!POTTS) {
+  float Wr[(POTTS || TRUNC > 0) ? 1 : A];
+  if constexpr (!POTTS && TRUNC == 0) {
 #pragma unroll
     for (int j = 0; j < A; j++) {
       const int a = s * A + j;
@@ -413,6 +423,31 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   const float wpot = POTTS ? Wuse[1] : 0.0f;
   // lanes past k: their message stays +inf (median with +inf is the maximum)
   const float potts_pad = bvalid ? -INF : INF;
+  // Truncated tables (TRUNC = n): W[a][b] = g[|a - b|] with g[d] = g[n + 1] for every d > n
+  // and g[d] <= g[n + 1] below (the host checks that before it picks this kernel).  Rounding
+  // is monotone, so with C = min_a fl(M[a] + g[n + 1]) over ALL sources
+  //   min_a fl(M[a] + W[a][b]) = min( min_{|a - b| <= n} fl(M[a] + g[|a - b|]), C ):
+  // a source further away than n contributes exactly its term of C, and a near source's term
+  // of C is not below its true candidate, so it cannot win wrongly.  The lowest source
+  // attaining the minimum is the lowest near source whose true candidate attains it or, when
+  // the minimum equals C, the lower of that and i_far, the lowest source whose term attains
+  // C (if i_far lies near b its true candidate attains the minimum as well).  The messages
+  // stay in registers: the near sources arrive through DPP row shifts (a chain is at most a
+  // row of sixteen lanes), with +inf as the weight where the shift would reach outside the
+  // chain's labels.
+  constexpr int NWT = TRUNC > 0 ? TRUNC : 1;
+  float tg0 = 0.0f, tfar = INF, tgm[NWT], tgp[NWT];
+  int trunc_arg = 0;
+  if constexpr (TRUNC > 0) {
+    tg0 = bvalid ? Wuse[0] : INF;
+#pragma unroll
+    for (int d = 1; d <= TRUNC; d++) {
+      const float g = d < k ? Wuse[d] : INF;  // W[0][d]
+      tgm[d - 1] = (bvalid && b - d >= 0) ? g : INF;
+      tgp[d - 1] = (bvalid && b + d < k) ? g : INF;
+    }
+    tfar = (bvalid && TRUNC + 1 < k) ? Wuse[TRUNC + 1] : INF;
+  }
   // Back-pointers of the Potts step: two lane masks per step, keep (the
   // minimum for target b is attained by b itself first) and eq (lanes whose
   // M + w equals the chain's C; the lowest one of a chain's field is i1).  Step
@@ -594,7 +629,9 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     if (DUAL) return;
     int arg = 0;
     if (live) {
-      if constexpr (RECOMP) {
+      if constexpr (TRUNC > 0) {
+        arg = trunc_arg;
+      } else if constexpr (RECOMP) {
         const f4_t c4 = m4_pend + w4_pend;
         const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
         arg = grp_pend | first_equal<4>(cc, best_pend);  // the lane that holds the source label
@@ -630,7 +667,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     // With one or two chains per wavefront the byte stored is the LANE that
     // holds the source label (label + chain slot * lanes per chain): the
     // backtrack then uses it as a v_readlane selector as it stands.
-    if constexpr (CPW <= 2 && !RECOMP) arg += cs * LPC;
+    if constexpr (SWALK && !RECOMP) arg += cs * LPC;
     acc = __builtin_amdgcn_alignbit((unsigned)arg, acc, 8);
     if ((SBP & 3) == 3) {
       if (s == ((SBP >> 2) % NS)) keep = acc;
@@ -681,6 +718,17 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // role_tag: 0 the whole step; SPLIT: 1 the shell's part (slot: the ring's block it fills),
   // 2 the recursion's part (thr: the block's adjusted unaries, fetched from the ring a block ago)
   float thr[SPLIT ? GPB : 1];
+  constexpr bool XPRE = TRUNC > 0 && NS == 1 && GPB % 4 == 0 && !DUAL && !SPLIT;
+  int xq_own[XPRE ? GPB : 1], xq_oth[XPRE ? GPB : 1], xn_own[XPRE ? GPB : 1], xn_oth[XPRE ? GPB : 1];
+  auto load_block_labels = [&](int *own, int *oth, const int at) {
+#pragma unroll
+    for (int q = 0; q < GPB / 4; q++) {
+      const int4 a = *reinterpret_cast<const int4 *>(&s_x[wib][cs][at + 4 * q]);
+      const int4 o = *reinterpret_cast<const int4 *>(&s_xo[wib][cs][at + 4 * q]);
+      own[4 * q + 0] = a.x; own[4 * q + 1] = a.y; own[4 * q + 2] = a.z; own[4 * q + 3] = a.w;
+      oth[4 * q + 0] = o.x; oth[4 * q + 1] = o.y; oth[4 * q + 2] = o.z; oth[4 * q + 3] = o.w;
+    }
+  };
   auto block = [&](const int tb, const int tt0, auto full_tag, auto role_tag, const int slot) {
     constexpr bool FULL = decltype(full_tag)::value;
     constexpr int ROLE = decltype(role_tag)::value;
@@ -690,15 +738,24 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       origin_block(tb);
     }
     int xown = -1, xoth = -1;  // labels of the current group (own step of this lane)
-    if (!DUAL && SHELL) {
+    if constexpr (XPRE) {
+      // the block's labels are in registers a block ahead of their use: a lone wavefront
+      // has nothing else to put in front of an LDS read's latency
+      if (tt0 == 0) {
+        load_block_labels(xq_own, xq_oth, 0);
+      } else {
+#pragma unroll
+        for (int q = 0; q < GPB; q++) { xq_own[q] = xn_own[q]; xq_oth[q] = xn_oth[q]; }
+      }
+    } else if (!DUAL && SHELL) {
       xown = s_x[wib][cs][tt0 + s];
       xoth = s_xo[wib][cs][tt0 + s];
     }
-    // Potts step on int16 counts: the shell of two steps at a time (PAIRED)
-    constexpr bool PAIRED = POTTS && LAM16 && GPB % 2 == 0;
+    // Potts or truncated step on integer counts: the shell of two steps at a time (PAIRED)
+    constexpr bool PAIRED = (POTTS || TRUNC > 0) && LAM16 && GPB % 2 == 0;
     int xown1 = -1, xoth1 = -1;  // labels of the step after the current one
     float th_pair = INF;         // adjusted unary of the odd step, worked out with the even one
-    if constexpr (PAIRED && SHELL) {
+    if constexpr (PAIRED && SHELL && !XPRE) {
       xown1 = s_x[wib][cs][tt0 + 1];
       xoth1 = s_xo[wib][cs][tt0 + 1];
     }
@@ -710,6 +767,15 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       const int n_in = __float_as_int(plam[SHELL ? j : 0]);  // LAM16: the count
       const float lam_in = LAM16 ? (float)n_in * shpen : __uint_as_float(__float_as_uint(plam[SHELL ? j : 0]) ^ lam_sign);
       const unsigned goff = soff0 + (unsigned)tg * sstep;  // uniform
+      if constexpr (XPRE) {
+        xown = xq_own[j];
+        xoth = xq_oth[j];
+        if constexpr (PAIRED && j % 2 == 0) {
+          xown1 = xq_own[j + 1];
+          xoth1 = xq_oth[j + 1];
+        }
+        if (j == GPB / 2 && tt0 + BLK < kChunk) load_block_labels(xn_own, xn_oth, tt0 + BLK);
+      }
       float th_own = INF;
       if constexpr (!SHELL) {
         th_own = thr[SPLIT ? j : 0];
@@ -779,7 +845,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         // (a) this step's messages leave LDS, with the next group's labels
         //     and the operands of the group one block ahead behind them ...
         f4 mv[(A + 3) / 4];
-        if (live && !POTTS && REC) {
+        if (live && !POTTS && REC && TRUNC == 0) {
           if constexpr (A % 4 == 0) {
             const f4 *mp = reinterpret_cast<const f4 *>(Mrow + (RECOMP ? ((j * NS + u) & 1) * MROW : 0) + s * A);
 #pragma unroll
@@ -791,13 +857,13 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         }
         if (u == NS - 1 && SHELL) {
           if constexpr (PAIRED) {
-            if (j % 2 == 1 && j + 1 < GPB) {
+            if (!XPRE && j % 2 == 1 && j + 1 < GPB) {
               xown = s_x[wib][cs][tt0 + j + 1];
               xoth = s_xo[wib][cs][tt0 + j + 1];
               xown1 = s_x[wib][cs][tt0 + j + 2];
               xoth1 = s_xo[wib][cs][tt0 + j + 2];
             }
-          } else if (!DUAL && j + 1 < GPB) {
+          } else if (!DUAL && !XPRE && j + 1 < GPB) {
             xown = s_x[wib][cs][tt0 + (j + 1) * NS + s];
             xoth = s_xo[wib][cs][tt0 + (j + 1) * NS + s];
           }
@@ -854,6 +920,72 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
                 : "s"((unsigned)keepm), "s"((unsigned)(keepm >> 32)), "s"((unsigned)eq), "s"((unsigned)(eq >> 32)), "s"(ls));
             Mreg = th_own + __builtin_amdgcn_fmed3f(Mreg, C1, potts_pad);
             if constexpr (PCOMP) origin_step(eq, keepm);
+          }
+        } else if constexpr (TRUNC > 0) {
+          if (live) {
+            // candidates of the near sources b - n .. b + n (DPP: lane b reads lane b -+ d of its
+            // row, 0 where the row ends, which the +inf weight covers) and of the far ones
+            static_assert(TRUNC == 0 || (TRUNC == 3 && KP == 16), "written out for three neighbours on either side and chains of one DPP row");
+            // A wavefront alone on its SIMD issues one instruction of any kind per turn, a wait
+            // state included, so the step is written out with the cross-lane minimum of the far
+            // term threaded through the near candidates: every DPP read then has its two
+            // instructions of distance from the write it depends on and no wait state is needed
+            // (the messages were written by the add that precedes this statement; the first two
+            // instructions read them without DPP).
+            float cm0, cm1, cm2, cp0, cp1, cp2, c0, cf, C, best, tmin, nlo, nhi;
+            asm("v_add_f32_e32 %[cf], %[M], %[wfar]\n\t"
+                "v_add_f32_e32 %[c0], %[M], %[w0]\n\t"
+                "v_add_f32_dpp %[cm0], %[M], %[wm0] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_add_f32_dpp %[cm1], %[M], %[wm1] row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_min_f32_dpp %[t], %[cf], %[cf] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                "v_add_f32_dpp %[cm2], %[M], %[wm2] row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_add_f32_dpp %[cp0], %[M], %[wp0] row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_min_f32_dpp %[t], %[t], %[t] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                "v_add_f32_dpp %[cp1], %[M], %[wp1] row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_add_f32_dpp %[cp2], %[M], %[wp2] row_shl:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_min_f32_dpp %[t], %[t], %[t] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                "v_min3_f32 %[nlo], %[c0], %[cm0], %[cm1]\n\t"
+                "v_min3_f32 %[nhi], %[cm2], %[cp0], %[cp1]\n\t"
+                "v_min_f32_dpp %[C], %[t], %[t] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                "v_min3_f32 %[best], %[nlo], %[nhi], %[cp2]\n\t"
+                "v_min_f32_e32 %[best], %[best], %[C]"
+                : [cf] "=&v"(cf), [c0] "=&v"(c0), [cm0] "=&v"(cm0), [cm1] "=&v"(cm1), [cm2] "=&v"(cm2), [cp0] "=&v"(cp0), [cp1] "=&v"(cp1),
+                  [cp2] "=&v"(cp2), [t] "=&v"(tmin), [nlo] "=&v"(nlo), [nhi] "=&v"(nhi), [C] "=&v"(C), [best] "=&v"(best)
+                : [M] "v"(Mreg), [wfar] "v"(tfar), [w0] "v"(tg0), [wm0] "v"(tgm[0]), [wm1] "v"(tgm[NWT > 1 ? 1 : 0]), [wm2] "v"(tgm[NWT > 2 ? 2 : 0]),
+                  [wp0] "v"(tgp[0]), [wp1] "v"(tgp[NWT > 1 ? 1 : 0]), [wp2] "v"(tgp[NWT > 2 ? 2 : 0]));
+            // lowest near source attaining the minimum, as an offset from b (64: none); a
+            // select reads the mask of the compare three instructions back, which covers the
+            // two wait states between a vector write of a scalar register and its use.  eqf:
+            // the lanes whose far term attains C; eqc: the lanes whose minimum is the far one.
+            int off;
+            unsigned long long eqf, eqc, ma, mb, mc;
+            asm("v_cmp_eq_f32_e64 %[ma], %[cp2], %[best]\n\t"
+                "v_cmp_eq_f32_e64 %[mb], %[cp1], %[best]\n\t"
+                "v_cmp_eq_f32_e64 %[mc], %[cp0], %[best]\n\t"
+                "v_cndmask_b32_e64 %[off], 64, 3, %[ma]\n\t"
+                "v_cmp_eq_f32_e64 %[ma], %[c0], %[best]\n\t"
+                "v_cndmask_b32_e64 %[off], %[off], 2, %[mb]\n\t"
+                "v_cmp_eq_f32_e64 %[mb], %[cm0], %[best]\n\t"
+                "v_cndmask_b32_e64 %[off], %[off], 1, %[mc]\n\t"
+                "v_cmp_eq_f32_e64 %[mc], %[cm1], %[best]\n\t"
+                "v_cndmask_b32_e64 %[off], %[off], 0, %[ma]\n\t"
+                "v_cmp_eq_f32_e64 %[ma], %[cm2], %[best]\n\t"
+                "v_cndmask_b32_e64 %[off], %[off], -1, %[mb]\n\t"
+                "v_cmp_eq_f32_e64 %[eqf], %[cf], %[C]\n\t"
+                "v_cmp_eq_f32_e64 %[eqc], %[best], %[C]\n\t"
+                "v_cndmask_b32_e64 %[off], %[off], -2, %[mc]\n\t"
+                "v_cndmask_b32_e64 %[off], %[off], -3, %[ma]"
+                : [off] "=&v"(off), [ma] "=&s"(ma), [mb] "=&s"(mb), [mc] "=&s"(mc), [eqf] "=&s"(eqf), [eqc] "=&s"(eqc)
+                : [cm0] "v"(cm0), [cm1] "v"(cm1), [cm2] "v"(cm2), [c0] "v"(c0), [cp0] "v"(cp0), [cp1] "v"(cp1), [cp2] "v"(cp2), [cf] "v"(cf),
+                  [C] "v"(C), [best] "v"(best));
+            // i_far: the lowest lane of this lane's chain whose far term attains C
+            const int ifar = __builtin_ctz((unsigned)(eqf >> (cs * LPC)) | (1u << (KP - 1)));
+            const int nearest = b + off;  // >= k when no near source attains the minimum (then it equals C)
+            const int lowest = min(nearest, ifar);
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(trunc_arg) : "v"(nearest), "v"(lowest), "s"(eqc));
+            // M_0 = t_0; a lane past k starts at +inf and stays there (its weights are +inf)
+            if (j == 0 && u == 0) best = (tb == 0) ? (bvalid ? 0.0f : INF) : best;
+            Mreg = th_own + best;
           }
         } else if (live) {
           float c[A];
@@ -1065,7 +1197,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // and hands the left half its last label.  Every wavefront of the
   // workgroup passes the same two barriers (one that has already returned is
   // not waited for).
-  if constexpr (POTTS) Mrow[b] = Mreg;
+  if constexpr (POTTS || TRUNC > 0) Mrow[b] = Mreg;
   wave_lds_fence();
   const float *Mlast = Mrow + (RECOMP ? (T & 1) * MROW : 0);  // step T-1 wrote row T & 1
   float bv = Mlast[b];
@@ -1095,6 +1227,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     for (int j = 0; j < A; j++) {
       float wj;
       if constexpr (POTTS) wj = (j < k && bvalid) ? (j == b ? 0.0f : wpot) : INF;
+      else if constexpr (TRUNC > 0) wj = (j < k && bvalid) ? Wuse[j * k + b] : INF;
       else wj = Wr[j];
       const float cnd = Mlast[s * A + j] + wj;
       if (cnd < gbest) { gbest = cnd; garg = s * A + j; }
@@ -1585,7 +1718,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     if (args.stamps && lane == 0) args.stamps[3 * (size_t)wave + 2] = __builtin_readcyclecounter();
     return;
   }
-  if constexpr (CPW <= 2) {
+  if constexpr (SWALK) {
     // One or two chains per wavefront: the walk runs on the scalar unit.  Lane
     // b keeps its label's sixteen back-pointer dwords of the chunk in
     // registers; a step is one v_readlane (lane = current label) and one bit

@@ -1,0 +1,24 @@
+"""Clock stamps of the sweep's wavefronts (forward pass, trace-back) on one problem.
+
+    python tools/gpu/stamps.py ROWS COLS K PAIRWISE [name=value ...]   (environment settings)
+"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+R, C, k = map(int, sys.argv[1:4])
+pairwise = sys.argv[4]
+for kv in sys.argv[5:]:
+    n, v = kv.split("=")
+    os.environ[n] = v
+import admm_amd as A  # noqa: E402
+g = A.Grid()
+g.SetPartitioner(A.ROW); g.SetPenalties(0.5, 1.0); g.SetGlobalInfo(R, C, k)
+g.Generate(seed=1, pairwise=pairwise); g.InitOptimization()
+print(g.SweepKernelName(), sys.argv[5:], flush=True)
+for _ in range(5):
+    g.Compute(); g.Update()
+g.Synchronize()
+os.environ["ADMM_SWEEP_STAMPS"] = "1"
+for _ in range(3):
+    g.Compute(); g.Update()
+g.Synchronize()
