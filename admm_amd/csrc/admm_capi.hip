@@ -371,6 +371,12 @@ void launch_sweep_potts_t(const ChainArgs &a, int blocks, hipStream_t s) {
 template <int KP, bool PCOMP = false>
 void launch_sweep_potts16_t(const ChainArgs &a, int blocks, hipStream_t s, bool lam8) {
   // (operands 16 steps ahead instead of 8: 1 to 2 % slower; 32: spills)
+  if constexpr (KP == 32 && !PCOMP) {
+    if (lam8 && getenv("ADMM_SWEEP_GPB16")) {
+      hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 16, 2, false, true, true, PCOMP, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+      return;
+    }
+  }
   if (lam8) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, PCOMP, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
   else hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, PCOMP>), dim3(blocks), dim3(kChainBlock), 0, s, a);
 }

@@ -454,6 +454,31 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // tt of a 64-step chunk goes to lane tt of four registers, which are stored
   // once per chunk: 16 bytes per step and wavefront instead of one per label.
   int vk0 = 0, vk1 = 0, ve0 = 0, ve1 = 0;
+  // PIPEB: the masks of a step are worked out one step late, threaded through the next
+  // step's chain of dependent instructions.  A wavefront that has its SIMD to itself issues
+  // one instruction of any kind every 4.8 clock ticks and waits 8.5 for a result it needs
+  // at once (16 behind a DPP move): the step's own chain - add, four-stage lane minimum, row
+  // swap, median, add - leaves two slots behind every link, and the compares, the scalar mask
+  // arithmetic and the lane write of the step before fit into exactly those.  The registers
+  // of the masks are pairs here (one 64-bit move per mask).
+  constexpr bool PIPEB = POTTS && !PCOMP && KP == 32;
+  unsigned long long vk64 = 0, ve64 = 0;
+  float pend_c = 0.0f, pend_C1 = 0.0f, pend_M = 0.0f;  // step whose masks are still to be written:
+  int pend_ls = 0;                                      // c, C1, the messages before it, its lane
+  bool pend = false;  // (nothing pending: the next step is lane 0 of a chunk, whose own masks overwrite what this writes)
+  auto mask_write = [&](const int ls, const unsigned long long keepm, const unsigned long long eq) {
+    asm("s_bfm_b64 exec, 1, %4\n\tv_mov_b64 %0, %2\n\tv_mov_b64 %1, %3\n\ts_mov_b64 exec, -1" : "+v"(vk64), "+v"(ve64) : "s"(keepm), "s"(eq), "s"(ls));
+  };
+  auto flush_pending = [&]() {
+    if (!pend) return;
+    const unsigned long long eq = __builtin_amdgcn_ballot_w64(pend_c == pend_C1);
+    const unsigned long long lt = __builtin_amdgcn_ballot_w64(pend_M < pend_C1);
+    const unsigned long long le = __builtin_amdgcn_ballot_w64(pend_M <= pend_C1);
+    const unsigned long long below = (eq - kFieldLsb<KP>) & ~eq;
+    mask_write(pend_ls, lt | (le & below), eq);
+    pend = false;
+    pend_ls = 0;
+  };
   float Mreg = bvalid ? 0.0f : INF;  // A_{-1}: min(0, 0 + w) = 0 makes the first step M_0 = t_0
   // Path compression for the trace-back.  The back-pointer of a Potts step is "keep the
   // label, or go to i1", so the composition of the back-pointers of a block of eight steps,
@@ -527,17 +552,29 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   auto buf_load = [&](const __amdgpu_buffer_rsrc_t &r, unsigned soff) -> float {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_off, soff, 0));
   };
-  // a multiplier: binary32, or (LAM16) the int16 count, sign-extended, as the bits of the float
-  auto lam_load = [&](unsigned step) -> float {
+  // a multiplier: binary32, or (LAM16) the int16 count, sign-extended, as the bits of the float.
+  // (SPLIT: the count stays in the width it was loaded in until it is used, count_of().
+  // Widened here, the compiler moves that instruction to where the two forms of the block
+  // meet again, the end of the round, with a wait for every load of the round in front of
+  // it: the memory latency of the prefetch, once per round.)
+  typedef typename std::conditional<SPLIT && LAM8, unsigned char, typename std::conditional<SPLIT && LAM16, unsigned short, float>::type>::type lamreg_t;
+  auto lam_load = [&](unsigned step) -> lamreg_t {
     if constexpr (LAM8) {
-      const signed char n = __builtin_bit_cast(signed char, __builtin_amdgcn_raw_buffer_load_b8(lam_rs, lane_off_c, soff0_l + step * sstep_l, 0));
-      return __int_as_float((int)n);
+      const unsigned char u = __builtin_amdgcn_raw_buffer_load_b8(lam_rs, lane_off_c, soff0_l + step * sstep_l, 0);
+      if constexpr (SPLIT) return u;
+      else return __int_as_float((int)__builtin_bit_cast(signed char, u));
     } else if constexpr (LAM16) {
-      const short n = __builtin_bit_cast(short, __builtin_amdgcn_raw_buffer_load_b16(lam_rs, lane_off_c, soff0_l + step * sstep_l, 0));
-      return __int_as_float((int)n);
+      const unsigned short u = __builtin_amdgcn_raw_buffer_load_b16(lam_rs, lane_off_c, soff0_l + step * sstep_l, 0);
+      if constexpr (SPLIT) return u;
+      else return __int_as_float((int)__builtin_bit_cast(short, u));
     } else {
       return buf_load(lam_rs, soff0 + step * sstep);
     }
+  };
+  auto count_of = [&](const lamreg_t raw) -> int {
+    if constexpr (SPLIT && LAM8) return (int)__builtin_bit_cast(signed char, raw);
+    else if constexpr (SPLIT && LAM16) return (int)__builtin_bit_cast(short, raw);
+    else return __float_as_int(raw);
   };
   // labels of the half in sweep order: xchain[xdir * step]
   label_t *xchain = sg.x + (long long)chain * Tfull + (rev ? Tfull - 1 : 0);
@@ -562,14 +599,39 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
 #pragma unroll
   for (int u = 0; u < NS; u++) m_addr[u] = (s == u) ? (cs * KP + b) : (CPW * KP + lane);
 
-  float pth[GPB], plam[GPB];
+  float pth[GPB];
+  lamreg_t plam[GPB];
 #pragma unroll
   for (int j = 0; j < GPB; j++) {
     const unsigned soff = soff0 + (unsigned)(j * NS) * sstep;
     pth[j] = (!SPLIT || role == 1) ? buf_load(th_rs, soff) : 0.0f;
-    plam[j] = (!SPLIT || role == 1) ? lam_load((unsigned)(j * NS)) : 0.0f;
+    plam[j] = (!SPLIT || role == 1) ? lam_load((unsigned)(j * NS)) : lamreg_t(0);
   }
-  int xnext = -1, xonext = -1;  // labels of the next 64-step chunk, in flight
+  // labels of the next 64-step chunk, in flight (lane i of a chain: steps i, i + LPC, ...)
+  constexpr int NXL = LPC >= kChunk ? 1 : kChunk / LPC;
+  constexpr bool XNEXT = NXL <= 4;  // narrower chains fill LDS at the chunk's end, with a wait for the loads
+  int xnext[NXL], xonext[NXL];
+#pragma unroll
+  for (int q = 0; q < NXL; q++) xnext[q] = xonext[q] = -1;
+  auto labels_fetch = [&](const int at) {  // at: first step of the chunk to fetch
+#pragma unroll
+    for (int q = 0; q < NXL; q++) {
+      const int i = within + q * LPC;
+      const bool ok = i < kChunk && at + i < T;
+      xnext[q] = ok ? xchain[xdir * (at + i)] : -1;
+      xonext[q] = ok ? xochain[xdir * (at + i)] : -1;
+    }
+  };
+  auto labels_to_lds = [&]() {
+#pragma unroll
+    for (int q = 0; q < NXL; q++) {
+      const int i = within + q * LPC;
+      if (i < kChunk) {
+        s_x[wib][cs][i] = xnext[q];
+        s_xo[wib][cs][i] = xonext[q];
+      }
+    }
+  };
   if (!DUAL && (!SPLIT || role == 1)) {
     for (int i = within; i < kChunk; i += LPC) {
       s_x[wib][cs][i] = (i < T) ? xchain[xdir * i] : -1;
@@ -764,8 +826,10 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       const int tg = tb + j * NS;
       const bool glive = FULL || tg < T;
       const float th_in = pth[SHELL ? j : 0];
-      const int n_in = __float_as_int(plam[SHELL ? j : 0]);  // LAM16: the count
-      const float lam_in = LAM16 ? (float)n_in * shpen : __uint_as_float(__float_as_uint(plam[SHELL ? j : 0]) ^ lam_sign);
+      const int n_in = LAM16 ? count_of(plam[SHELL ? j : 0]) : 0;  // LAM16: the count
+      float lam_in;
+      if constexpr (LAM16) lam_in = (float)n_in * shpen;
+      else lam_in = __uint_as_float(__float_as_uint(plam[SHELL ? j : 0]) ^ lam_sign);
       const unsigned goff = soff0 + (unsigned)tg * sstep;  // uniform
       if constexpr (XPRE) {
         xown = xq_own[j];
@@ -795,7 +859,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
           // compiler takes a 64-bit multiply-add for it)
           int m0, m1;
           asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(m0) : "v"(n_in), "s"(sgn), "v"(d0));
-          asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(m1) : "v"(__float_as_int(plam[j + 1])), "s"(sgn), "v"(d1));
+          asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(m1) : "v"(count_of(plam[j + 1])), "s"(sgn), "v"(d1));
           const f2 hp2 = {hpen, hpen}, rho2 = {rho, rho};
           const f2 la2 = f2{(float)m0, (float)m1} * hp2;   // Tree.cpp:70
           const f2 p2 = f2{(float)d0, (float)d1} * hp2;
@@ -899,6 +963,47 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         if constexpr (!REC) {
         } else if constexpr (POTTS) {
           if (live) {
+            if constexpr (PIPEB && FULL) {
+              const int ls = tt0 + j;
+              float c, C1, r, t, Mnew;
+              unsigned long long m_lt, m_le, m_eq;
+              asm("v_add_f32_e32 %[c], %[M], %[wp]\n\t"
+                  "v_cmp_eq_f32_e32 vcc, %[pc], %[pC]\n\t"
+                  "v_cmp_lt_f32_e64 %[LT], %[pM], %[pC]\n\t"
+                  "v_min_f32_dpp %[r], %[c], %[c] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                  "v_cmp_le_f32_e64 %[LE], %[pM], %[pC]\n\t"
+                  "s_mov_b64 %[E], vcc\n\t"
+                  "v_min_f32_dpp %[r], %[r], %[r] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                  "s_sub_u32 vcc_lo, vcc_lo, %[l0]\n\t"
+                  "s_subb_u32 vcc_hi, vcc_hi, %[l1]\n\t"
+                  "v_min_f32_dpp %[r], %[r], %[r] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                  "s_andn2_b64 vcc, vcc, %[E]\n\t"
+                  "s_and_b64 vcc, vcc, %[LE]\n\t"
+                  "v_min_f32_dpp %[r], %[r], %[r] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                  "s_or_b64 %[LE], vcc, %[LT]\n\t"
+                  "s_bfm_b64 exec, 1, %[ls]\n\t"
+                  "v_mov_b64 %[vk], %[LE]\n\t"
+                  "v_mov_b64 %[ve], %[E]\n\t"
+                  "s_mov_b64 exec, -1\n\t"
+                  "v_mov_b32 %[t], %[r]\n\t"
+                  "s_nop 1\n\t"
+                  "v_permlane16_swap_b32 %[r], %[t]\n\t"
+                  "v_min_f32_e32 %[C], %[r], %[t]\n\t"
+                  "v_med3_f32 %[t], %[M], %[C], %[pad]\n\t"
+                  "v_add_f32_e32 %[Mo], %[th], %[t]"
+                  : [c] "=&v"(c), [r] "=&v"(r), [t] "=&v"(t), [C] "=&v"(C1), [Mo] "=&v"(Mnew), [LT] "=&s"(m_lt), [LE] "=&s"(m_le), [E] "=&s"(m_eq),
+                    [vk] "+v"(vk64), [ve] "+v"(ve64)
+                  : [M] "v"(Mreg), [wp] "v"(wpot), [pc] "v"(pend_c), [pC] "v"(pend_C1), [pM] "v"(pend_M), [th] "v"(th_own), [pad] "v"(potts_pad),
+                    [ls] "s"(pend_ls), [l0] "n"((unsigned)kFieldLsb<KP>), [l1] "n"((unsigned)(kFieldLsb<KP> >> 32))
+                  : "vcc", "scc");
+              pend_c = c;
+              pend_C1 = C1;
+              pend_M = Mreg;
+              pend_ls = ls;
+              pend = true;
+              Mreg = Mnew;
+            } else {
+            if constexpr (PIPEB) flush_pending();
             const float c = Mreg + wpot;
             const float C1 = chain_lanes_min<KP>(c);
             const unsigned long long eq = __builtin_amdgcn_ballot_w64(c == C1);
@@ -909,6 +1014,9 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
             const unsigned long long below = (eq - kFieldLsb<KP>) & ~eq;
             const unsigned long long keepm = lt | (le & below);
             const int ls = tt0 + j;  // the step's place in its chunk (uniform)
+            if constexpr (PIPEB) {
+              mask_write(ls, keepm, eq);
+            } else {
             // into lane ls of the four registers: moves with only that lane enabled (a
             // lane write takes one scalar operand, and the lane would be a second)
             // (s_bfm: one set bit at the offset, and unlike a shift it leaves the
@@ -918,8 +1026,10 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
                 "s_mov_b64 exec, -1"
                 : "+v"(vk0), "+v"(vk1), "+v"(ve0), "+v"(ve1)
                 : "s"((unsigned)keepm), "s"((unsigned)(keepm >> 32)), "s"((unsigned)eq), "s"((unsigned)(eq >> 32)), "s"(ls));
+            }
             Mreg = th_own + __builtin_amdgcn_fmed3f(Mreg, C1, potts_pad);
             if constexpr (PCOMP) origin_step(eq, keepm);
+            }
           }
         } else if constexpr (TRUNC > 0) {
           if (live) {
@@ -1063,32 +1173,38 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     }
   };
   if constexpr (!SPLIT) {
-  for (int t0 = 0; t0 < T; t0 += kChunk) {
+  // One chunk of 64 steps.  Whole chunks run in a loop of their own and the chain's last,
+  // partial one after it: in one loop the two forms of the body meet again at its end with
+  // the prefetched operands in different registers, and the copies that reconcile them wait
+  // for every load in flight - the memory latency once per chunk, which a wavefront that is
+  // alone on its SIMD has nothing to cover with.
+  auto chunk = [&](const int t0, auto whole_tag) {
+    constexpr bool WHOLE = decltype(whole_tag)::value;
     set_prio(prio_slot + t0 / kChunk);
     if (!DUAL) {
       // labels of chunk t0 are in LDS; fetch the next chunk's while this one runs
-      if (LPC >= kChunk) {
-        const bool ok = t0 + kChunk + within < T;
-        xnext = ok ? xchain[xdir * (t0 + kChunk + within)] : -1;
-        xonext = ok ? xochain[xdir * (t0 + kChunk + within)] : -1;
-      }
+      if constexpr (XNEXT) labels_fetch(t0 + kChunk);
     }
-    if (t0 + kChunk <= T) {
+    if constexpr (WHOLE) {
 #pragma unroll 2
       for (int tt = 0; tt < kChunk; tt += BLK) block(t0 + tt, tt, std::true_type{}, std::integral_constant<int, 0>{}, 0);
     } else {
 #pragma unroll 1
-      for (int tt = 0; tt < kChunk && t0 + tt < T; tt += BLK) block(t0 + tt, tt, std::false_type{}, std::integral_constant<int, 0>{}, 0);  // tail
+      for (int tt = 0; tt < kChunk && t0 + tt < T; tt += BLK) block(t0 + tt, tt, std::false_type{}, std::integral_constant<int, 0>{}, 0);
     }
     if constexpr (POTTS) {
       uint32_t *o = bpwave + (t0 / kChunk) * 256 + lane;
-      o[0] = (uint32_t)vk0; o[64] = (uint32_t)vk1; o[128] = (uint32_t)ve0; o[192] = (uint32_t)ve1;
+      if constexpr (PIPEB) {
+        flush_pending();
+        o[0] = (uint32_t)vk64; o[64] = (uint32_t)(vk64 >> 32); o[128] = (uint32_t)ve64; o[192] = (uint32_t)(ve64 >> 32);
+      } else {
+        o[0] = (uint32_t)vk0; o[64] = (uint32_t)vk1; o[128] = (uint32_t)ve0; o[192] = (uint32_t)ve1;
+      }
     }
-    if (!DUAL && t0 + kChunk < T) {
+    if (!DUAL && WHOLE && t0 + kChunk < T) {
       wave_lds_fence();
-      if (LPC >= kChunk) {
-        s_x[wib][cs][within] = xnext;
-        s_xo[wib][cs][within] = xonext;
+      if constexpr (XNEXT) {
+        labels_to_lds();
       } else {
         for (int i = within; i < kChunk; i += LPC) {
           const bool ok = t0 + kChunk + i < T;
@@ -1098,7 +1214,10 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       }
       wave_lds_fence();
     }
-  }
+  };
+  int t0 = 0;
+  for (; t0 + kChunk <= T; t0 += kChunk) chunk(t0, std::true_type{});
+  if (t0 < T) chunk(t0, std::false_type{});
 
   } else {
     // Two wavefronts per half chain.  In round ib the shell works on block ib and the
@@ -1108,58 +1227,91 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     const int nblk = (Lhalf + BLK - 1) / BLK;
     typedef std::integral_constant<int, 1> shell_t;
     typedef std::integral_constant<int, 2> rec_t;
-    for (int ib = 0; ib < nblk + 2; ib++) {
-      if (role == 1) {
-        const int tb = ib * BLK, tt = tb & (kChunk - 1);
-        if (tb < T) {
-          if (tt == 0 && LPC >= kChunk) {
-            // labels of this chunk are in LDS; fetch the next chunk's while this one runs
-            const bool ok = tb + kChunk + within < T;
-            xnext = ok ? xchain[xdir * (tb + kChunk + within)] : -1;
-            xonext = ok ? xochain[xdir * (tb + kChunk + within)] : -1;
-          }
-          if (tb + BLK <= T) block(tb, tt, std::true_type{}, shell_t{}, ib % 3);
-          else block(tb, tt, std::false_type{}, shell_t{}, ib % 3);
-          if (tt + BLK == kChunk && tb + BLK < T) {
-            const int t0 = tb - tt;
-            wave_lds_fence();
-            if (LPC >= kChunk) {
-              s_x[wib][cs][within] = xnext;
-              s_xo[wib][cs][within] = xonext;
-            } else {
-              for (int i = within; i < kChunk; i += LPC) {
-                const bool ok = t0 + kChunk + i < T;
-                s_x[wib][cs][i] = ok ? xchain[xdir * (t0 + kChunk + i)] : -1;
-                s_xo[wib][cs][i] = ok ? xochain[xdir * (t0 + kChunk + i)] : -1;
-              }
-            }
-            wave_lds_fence();
-          }
-        }
-      } else {
-        if (ib >= 2) {
-          const int tb = (ib - 2) * BLK, tt = tb & (kChunk - 1);
-          if (tb < T) {
-            if (tb + BLK <= T) block(tb, tt, std::true_type{}, rec_t{}, 0);
-            else block(tb, tt, std::false_type{}, rec_t{}, 0);
-            if constexpr (POTTS) {
-              if (tt + BLK == kChunk || tb + BLK >= T) {
-                uint32_t *o = bpwave + (tb / kChunk) * 256 + lane;
-                o[0] = (uint32_t)vk0; o[64] = (uint32_t)vk1; o[128] = (uint32_t)ve0; o[192] = (uint32_t)ve1;
-              }
-            }
-          }
-        }
-        if (ib >= 1 && (ib - 1) * BLK < T) {
-          // the block the shell finished a round ago, for the next round
-#pragma unroll
-          for (int j = 0; j < GPB; j++) thr[SPLIT ? j : 0] = s_ring[rev][((ib - 1) % 3) * GPB + j][lane];
-        }
-      }
+    // Each role has its rounds in loops of its own, whole blocks apart from the last, partial
+    // one: where two forms of a round meet again the compiler reconciles their registers with
+    // copies, and copies of operands still in flight wait for the loads - the memory latency
+    // of the prefetch once per round.
+    auto round_end = [&]() {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    const int nwhole = T / BLK;  // whole blocks of this half
+    int ib = 0;
+    if (role == 1) {
+      auto shell_round = [&](const int ib, auto full_tag) {
+        const int tb = ib * BLK, tt = tb & (kChunk - 1);
+        if (tt == 0) {
+          // labels of this chunk are in LDS; fetch the next chunk's while this one runs
+          if constexpr (XNEXT) labels_fetch(tb + kChunk);
+        }
+        block(tb, tt, full_tag, shell_t{}, ib % 3);
+        if (tt + BLK == kChunk && tb + BLK < T) {
+          const int t0 = tb - tt;
+          wave_lds_fence();
+          if constexpr (XNEXT) {
+            labels_to_lds();
+          } else {
+            for (int i = within; i < kChunk; i += LPC) {
+              const bool ok = t0 + kChunk + i < T;
+              s_x[wib][cs][i] = ok ? xchain[xdir * (t0 + kChunk + i)] : -1;
+              s_xo[wib][cs][i] = ok ? xochain[xdir * (t0 + kChunk + i)] : -1;
+            }
+          }
+          wave_lds_fence();
+        }
+      };
+      // (every load issued so far has landed before the loop starts: the waits inside it
+      // then count the loop's own loads only, instead of waiting for all of them at its head)
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+      for (; ib < nwhole; ib++) {
+        shell_round(ib, std::true_type{});
+        round_end();
+      }
+      if (ib * BLK < T) {
+        shell_round(ib, std::false_type{});
+        round_end();
+        ib++;
+      }
+    } else {
+      auto rec_round = [&](const int ib, auto full_tag) {  // block ib - 2, then the ring's block ib - 1
+        const int tb = (ib - 2) * BLK, tt = tb & (kChunk - 1);
+        block(tb, tt, full_tag, rec_t{}, 0);
+        if constexpr (POTTS) {
+          if (tt + BLK == kChunk || tb + BLK >= T) {
+            uint32_t *o = bpwave + (tb / kChunk) * 256 + lane;
+            if constexpr (PIPEB) {
+              flush_pending();
+              o[0] = (uint32_t)vk64; o[64] = (uint32_t)(vk64 >> 32); o[128] = (uint32_t)ve64; o[192] = (uint32_t)(ve64 >> 32);
+            } else {
+              o[0] = (uint32_t)vk0; o[64] = (uint32_t)vk1; o[128] = (uint32_t)ve0; o[192] = (uint32_t)ve1;
+            }
+          }
+        }
+      };
+      auto ring_fetch = [&](const int blk) {  // the block the shell finished a round ago, for the next round
+        if (blk * BLK < T) {
+#pragma unroll
+          for (int j = 0; j < GPB; j++) thr[SPLIT ? j : 0] = s_ring[rev][(blk % 3) * GPB + j][lane];
+        }
+      };
+      round_end();  // round 0: the shell's first block
+      ib = 1;
+      ring_fetch(0);
+      round_end();
+      ib = 2;
+      for (; ib < nwhole + 2; ib++) {
+        rec_round(ib, std::true_type{});
+        ring_fetch(ib - 1);
+        round_end();
+      }
+      if ((ib - 2) * BLK < T) {
+        rec_round(ib, std::false_type{});
+        round_end();
+        ib++;
+      }
     }
+    for (; ib < nblk + 2; ib++) round_end();
     if (role == 1) {
       // the shell's share of the results: the unary term of the objective; then it is done
       // (the barriers of the join do not wait for wavefronts that have ended)

@@ -48,6 +48,61 @@ __global__ void chain_kernel(float *out, unsigned long long *ticks, float seed) 
         int m;
         asm volatile("v_bfe_i32 %1, %2, %0, 1\n\tv_bfi_b32 %0, %1, %0, %3" : "+v"(c), "=&v"(m) : "v"(kw), "v"(i1));
       }
+    } else if constexpr (KIND == 8) {  // 8 independent cross-lane adds (row shift)
+      asm volatile("v_add_f32_dpp %0, %8, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_add_f32_dpp %1, %8, %8 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                   "v_add_f32_dpp %2, %8, %8 row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_add_f32_dpp %3, %8, %8 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                   "v_add_f32_dpp %4, %8, %8 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_add_f32_dpp %5, %8, %8 row_shl:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                   "v_add_f32_dpp %6, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_add_f32_dpp %7, %8, %8 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                   : "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3), "=&v"(y4), "=&v"(y5), "=&v"(y6), "=&v"(y7) : "v"(seed));
+    } else if constexpr (KIND == 9) {  // 8 independent compares into scalar register pairs
+      unsigned long long m0, m1, m2, m3;
+      asm volatile("v_cmp_eq_f32_e64 %0, %4, %5\n\tv_cmp_eq_f32_e64 %1, %4, %6\n\tv_cmp_eq_f32_e64 %2, %4, %7\n\tv_cmp_eq_f32_e64 %3, %4, %8\n\t"
+                   "v_cmp_eq_f32_e64 %0, %5, %6\n\tv_cmp_eq_f32_e64 %1, %5, %7\n\tv_cmp_eq_f32_e64 %2, %5, %8\n\tv_cmp_eq_f32_e64 %3, %6, %7"
+                   : "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3) : "v"(seed), "v"(y0), "v"(y1), "v"(y2), "v"(y3));
+      c += (int)(m0 + m1 + m2 + m3 == 77);
+    } else if constexpr (KIND == 10) {  // 4 compares and the 4 selects on them, three instructions apart
+      unsigned long long m0, m1, m2;
+      asm volatile("v_cmp_eq_f32_e64 %1, %4, %5\n\tv_cmp_eq_f32_e64 %2, %4, %6\n\tv_cmp_eq_f32_e64 %3, %4, %7\n\t"
+                   "v_cndmask_b32_e64 %0, %0, 3, %1\n\tv_cmp_eq_f32_e64 %1, %4, %8\n\tv_cndmask_b32_e64 %0, %0, 2, %2\n\t"
+                   "v_cndmask_b32_e64 %0, %0, 1, %3\n\tv_cndmask_b32_e64 %0, %0, 0, %1"
+                   : "+v"(c), "=&s"(m0), "=&s"(m1), "=&s"(m2) : "v"(seed), "v"(y0), "v"(y1), "v"(y2), "v"(y3));
+    } else if constexpr (KIND == 11) {  // 8 independent three-way minima
+      asm volatile("v_min3_f32 %0, %0, %8, %1\n\tv_min3_f32 %1, %1, %8, %2\n\tv_min3_f32 %2, %2, %8, %3\n\tv_min3_f32 %3, %3, %8, %4\n\t"
+                   "v_min3_f32 %4, %4, %8, %5\n\tv_min3_f32 %5, %5, %8, %6\n\tv_min3_f32 %6, %6, %8, %7\n\tv_min3_f32 %7, %7, %8, %8"
+                   : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7) : "v"(seed));
+    } else if constexpr (KIND == 12) {  // 8 independent 64-bit shifts of a scalar pair
+      unsigned long long a0, a1, a2, a3;
+      const unsigned long long sm = __builtin_amdgcn_ballot_w64(threadIdx.x & 1);
+      asm volatile("v_lshrrev_b64 %0, %4, %5\n\tv_lshrrev_b64 %1, %4, %5\n\tv_lshrrev_b64 %2, %4, %5\n\tv_lshrrev_b64 %3, %4, %5\n\t"
+                   "v_lshrrev_b64 %0, %4, %5\n\tv_lshrrev_b64 %1, %4, %5\n\tv_lshrrev_b64 %2, %4, %5\n\tv_lshrrev_b64 %3, %4, %5"
+                   : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3) : "v"(c), "s"(sm));
+      kw += (unsigned)(a0 + a1 + a2 + a3);
+    } else if constexpr (KIND == 13) {  // 8 wait states, one instruction each
+      asm volatile("s_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0");
+    } else if constexpr (KIND == 14) {  // 8 dependent scalar adds
+      int sa = it;
+      asm volatile("s_add_i32 %0, %0, 1\n\ts_add_i32 %0, %0, 1\n\ts_add_i32 %0, %0, 1\n\ts_add_i32 %0, %0, 1\n\t"
+                   "s_add_i32 %0, %0, 1\n\ts_add_i32 %0, %0, 1\n\ts_add_i32 %0, %0, 1\n\ts_add_i32 %0, %0, 1" : "+s"(sa) : : "scc");
+      c += sa & 1;
+    } else if constexpr (KIND == 15) {  // 8 independent vector adds with a scalar add behind each
+      int sa = it;
+      asm volatile("v_add_f32_e32 %0, %0, %9\n\ts_add_i32 %8, %8, 1\n\tv_add_f32_e32 %1, %1, %9\n\ts_add_i32 %8, %8, 1\n\t"
+                   "v_add_f32_e32 %2, %2, %9\n\ts_add_i32 %8, %8, 1\n\tv_add_f32_e32 %3, %3, %9\n\ts_add_i32 %8, %8, 1\n\t"
+                   "v_add_f32_e32 %4, %4, %9\n\ts_add_i32 %8, %8, 1\n\tv_add_f32_e32 %5, %5, %9\n\ts_add_i32 %8, %8, 1\n\t"
+                   "v_add_f32_e32 %6, %6, %9\n\ts_add_i32 %8, %8, 1\n\tv_add_f32_e32 %7, %7, %9\n\ts_add_i32 %8, %8, 1"
+                   : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7), "+s"(sa) : "v"(seed) : "scc");
+      c += sa & 1;
+    } else if constexpr (KIND == 16) {  // 2 dependent adds with 3 independent ones between them
+      asm volatile("v_add_f32_e32 %0, %0, %8\n\tv_add_f32_e32 %1, %1, %8\n\tv_add_f32_e32 %2, %2, %8\n\tv_add_f32_e32 %3, %3, %8\n\t"
+                   "v_add_f32_e32 %0, %0, %8\n\tv_add_f32_e32 %1, %1, %8\n\tv_add_f32_e32 %2, %2, %8\n\tv_add_f32_e32 %3, %3, %8"
+                   : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7) : "v"(seed));
+    } else if constexpr (KIND == 17) {  // 8 independent packed adds
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      f2 p0 = {y0, y1}, p1 = {y2, y3}, p2 = {y4, y5}, p3 = {y6, y7}, sd = {seed, seed};
+      asm volatile("v_pk_add_f32 %0, %0, %4\n\tv_pk_add_f32 %1, %1, %4\n\tv_pk_add_f32 %2, %2, %4\n\tv_pk_add_f32 %3, %3, %4\n\t"
+                   "v_pk_add_f32 %0, %0, %4\n\tv_pk_add_f32 %1, %1, %4\n\tv_pk_add_f32 %2, %2, %4\n\tv_pk_add_f32 %3, %3, %4"
+                   : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(sd));
+      y0 = p0.x; y1 = p0.y; y2 = p1.x; y3 = p1.y; y4 = p2.x; y5 = p2.y; y6 = p3.x; y7 = p3.y;
     } else {  // one full 32-lane minimum as the Potts step does it, then the median and the add that close the step
       float r, t;
       asm volatile("v_add_f32_e32 %0, %2, %3\n\t"
@@ -95,6 +150,16 @@ int main() {
   run<4>("dependent copy, v_permlane16_swap, minimum", 8, d_out, d_t);
   run<5>("walk step: v_bfe_u32, v_cmp, v_cndmask", 8, d_out, d_t);
   run<6>("walk step: v_bfe_i32, v_bfi_b32", 8, d_out, d_t);
+  run<8>("independent v_add_f32_dpp row shifts", 8, d_out, d_t);
+  run<9>("independent v_cmp_eq_f32 into scalar pairs", 8, d_out, d_t);
+  run<10>("4 compares + 4 selects, three apart", 8, d_out, d_t);
+  run<11>("independent v_min3_f32", 8, d_out, d_t);
+  run<12>("independent v_lshrrev_b64", 8, d_out, d_t);
+  run<13>("s_nop 0", 8, d_out, d_t);
+  run<14>("dependent s_add_i32", 8, d_out, d_t);
+  run<15>("v_add_f32 and s_add_i32 alternating (16 instructions)", 16, d_out, d_t);
+  run<16>("v_add_f32, dependent at distance four", 8, d_out, d_t);
+  run<17>("v_pk_add_f32, dependent at distance four", 8, d_out, d_t);
   run<7>("Potts chain: add, 32-lane minimum, median, add", 1, d_out, d_t);
   hipFree(d_out); hipFree(d_t);
   return 0;

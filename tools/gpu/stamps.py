@@ -1,17 +1,21 @@
 """Clock stamps of the sweep's wavefronts (forward pass, trace-back) on one problem.
 
-    python tools/gpu/stamps.py ROWS COLS K PAIRWISE [name=value ...]   (environment settings)
+    python tools/gpu/stamps.py ROWS COLS K PAIRWISE [strips=G] [name=value ...]   (environment settings)
 """
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 R, C, k = map(int, sys.argv[1:4])
 pairwise = sys.argv[4]
+G = 1
 for kv in sys.argv[5:]:
     n, v = kv.split("=")
-    os.environ[n] = v
+    if n == "strips":   # strip 0 of that many, alone
+        G = int(v)
+    else:
+        os.environ[n] = v
 import admm_amd as A  # noqa: E402
-g = A.Grid()
+g = A.Grid(rank=0, nprocs=G)
 g.SetPartitioner(A.ROW); g.SetPenalties(0.5, 1.0); g.SetGlobalInfo(R, C, k)
 g.Generate(seed=1, pairwise=pairwise); g.InitOptimization()
 print(g.SweepKernelName(), sys.argv[5:], flush=True)
