@@ -353,11 +353,12 @@ void launch_sweep_t(const ChainArgs &a, int blocks, hipStream_t s) {
 bool twowave_chosen(int KP, int waves) {
   if (KP != 32) return false;
   if (const char *e = getenv("ADMM_SWEEP_TWOWAVE")) return atoi(e) != 0;
-  return waves <= 512;
+  return waves <= 1024;
 }
 template <int KP>
 void launch_sweep_potts_split_t(const ChainArgs &a, int blocks, hipStream_t s, bool lam16, bool lam8) {
-  if (lam8) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, false, true, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+  if (lam8 && getenv("ADMM_SWEEP_GPB16")) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 16, 2, false, true, true, false, true, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+  else if (lam8) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, false, true, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
   else if (lam16) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, false, false, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
   else hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, false, false, false, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
 }

@@ -461,23 +461,13 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // swap, median, add - leaves two slots behind every link, and the compares, the scalar mask
   // arithmetic and the lane write of the step before fit into exactly those.  The registers
   // of the masks are pairs here (one 64-bit move per mask).
-  constexpr bool PIPEB = POTTS && !PCOMP && KP == 32;
+  constexpr bool PIPEB = POTTS && KP >= 8;
   unsigned long long vk64 = 0, ve64 = 0;
   float pend_c = 0.0f, pend_C1 = 0.0f, pend_M = 0.0f;  // step whose masks are still to be written:
   int pend_ls = 0;                                      // c, C1, the messages before it, its lane
   bool pend = false;  // (nothing pending: the next step is lane 0 of a chunk, whose own masks overwrite what this writes)
   auto mask_write = [&](const int ls, const unsigned long long keepm, const unsigned long long eq) {
     asm("s_bfm_b64 exec, 1, %4\n\tv_mov_b64 %0, %2\n\tv_mov_b64 %1, %3\n\ts_mov_b64 exec, -1" : "+v"(vk64), "+v"(ve64) : "s"(keepm), "s"(eq), "s"(ls));
-  };
-  auto flush_pending = [&]() {
-    if (!pend) return;
-    const unsigned long long eq = __builtin_amdgcn_ballot_w64(pend_c == pend_C1);
-    const unsigned long long lt = __builtin_amdgcn_ballot_w64(pend_M < pend_C1);
-    const unsigned long long le = __builtin_amdgcn_ballot_w64(pend_M <= pend_C1);
-    const unsigned long long below = (eq - kFieldLsb<KP>) & ~eq;
-    mask_write(pend_ls, lt | (le & below), eq);
-    pend = false;
-    pend_ls = 0;
   };
   float Mreg = bvalid ? 0.0f : INF;  // A_{-1}: min(0, 0 + w) = 0 makes the first step M_0 = t_0
   // Path compression for the trace-back.  The back-pointer of a Potts step is "keep the
@@ -773,6 +763,19 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     org = lane;
   };
 
+  // the masks of the step still pending (PIPEB), outside the next step's instructions
+  auto flush_pending = [&]() {
+    if (!pend) return;
+    const unsigned long long eq = __builtin_amdgcn_ballot_w64(pend_c == pend_C1);
+    const unsigned long long lt = __builtin_amdgcn_ballot_w64(pend_M < pend_C1);
+    const unsigned long long le = __builtin_amdgcn_ballot_w64(pend_M <= pend_C1);
+    const unsigned long long below = (eq - kFieldLsb<KP>) & ~eq;
+    mask_write(pend_ls, lt | (le & below), eq);
+    if constexpr (PCOMP) origin_step(eq, lt | (le & below));
+    pend = false;
+    pend_ls = 0;
+  };
+
   // One unrolled block of BLK steps starting at step tb (tt0 = tb - chunk start).
   // The order inside a step is pinned with scheduling barriers: LDS reads
   // first, then the previous step's arg-min (it covers the LDS latency), then
@@ -797,7 +800,10 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     constexpr bool SHELL = ROLE != 2, REC = ROLE != 1;
     if constexpr (PCOMP && REC) {
       static_assert(!PCOMP || BLK == 8, "the trace-back's records are one per unrolled block of eight steps");
-      origin_block(tb);
+      // (PIPEB, whole block: the last step of the block before is still pending; the block's
+      // first step settles it and starts the new record then)
+      if constexpr (PIPEB && !FULL) flush_pending();
+      if constexpr (!(PIPEB && FULL)) origin_block(tb);
     }
     int xown = -1, xoth = -1;  // labels of the current group (own step of this lane)
     if constexpr (XPRE) {
@@ -967,35 +973,60 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
               const int ls = tt0 + j;
               float c, C1, r, t, Mnew;
               unsigned long long m_lt, m_le, m_eq;
-              asm("v_add_f32_e32 %[c], %[M], %[wp]\n\t"
-                  "v_cmp_eq_f32_e32 vcc, %[pc], %[pC]\n\t"
-                  "v_cmp_lt_f32_e64 %[LT], %[pM], %[pC]\n\t"
-                  "v_min_f32_dpp %[r], %[c], %[c] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                  "v_cmp_le_f32_e64 %[LE], %[pM], %[pC]\n\t"
-                  "s_mov_b64 %[E], vcc\n\t"
-                  "v_min_f32_dpp %[r], %[r], %[r] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                  "s_sub_u32 vcc_lo, vcc_lo, %[l0]\n\t"
-                  "s_subb_u32 vcc_hi, vcc_hi, %[l1]\n\t"
-                  "v_min_f32_dpp %[r], %[r], %[r] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                  "s_andn2_b64 vcc, vcc, %[E]\n\t"
-                  "s_and_b64 vcc, vcc, %[LE]\n\t"
-                  "v_min_f32_dpp %[r], %[r], %[r] row_mirror row_mask:0xf bank_mask:0xf\n\t"
-                  "s_or_b64 %[LE], vcc, %[LT]\n\t"
-                  "s_bfm_b64 exec, 1, %[ls]\n\t"
-                  "v_mov_b64 %[vk], %[LE]\n\t"
-                  "v_mov_b64 %[ve], %[E]\n\t"
-                  "s_mov_b64 exec, -1\n\t"
-                  "v_mov_b32 %[t], %[r]\n\t"
-                  "s_nop 1\n\t"
-                  "v_permlane16_swap_b32 %[r], %[t]\n\t"
-                  "v_min_f32_e32 %[C], %[r], %[t]\n\t"
-                  "v_med3_f32 %[t], %[M], %[C], %[pad]\n\t"
-                  "v_add_f32_e32 %[Mo], %[th], %[t]"
-                  : [c] "=&v"(c), [r] "=&v"(r), [t] "=&v"(t), [C] "=&v"(C1), [Mo] "=&v"(Mnew), [LT] "=&s"(m_lt), [LE] "=&s"(m_le), [E] "=&s"(m_eq),
-                    [vk] "+v"(vk64), [ve] "+v"(ve64)
-                  : [M] "v"(Mreg), [wp] "v"(wpot), [pc] "v"(pend_c), [pC] "v"(pend_C1), [pM] "v"(pend_M), [th] "v"(th_own), [pad] "v"(potts_pad),
-                    [ls] "s"(pend_ls), [l0] "n"((unsigned)kFieldLsb<KP>), [l1] "n"((unsigned)(kFieldLsb<KP> >> 32))
-                  : "vcc", "scc");
+              // c = M + w and the first two stages of its minimum over the chain's lanes, with
+              // the three compares of the step before, the copy of eq and eq - (lowest bit of
+              // every field) between them
+#define ADMM_PB_HEAD                                                                                  \
+  "v_add_f32_e32 %[c], %[M], %[wp]\n\t"                                                               \
+  "v_cmp_eq_f32_e32 vcc, %[pc], %[pC]\n\t"                                                            \
+  "v_cmp_lt_f32_e64 %[LT], %[pM], %[pC]\n\t"                                                          \
+  "v_min_f32_dpp %[r], %[c], %[c] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                 \
+  "v_cmp_le_f32_e64 %[LE], %[pM], %[pC]\n\t"                                                          \
+  "s_mov_b64 %[E], vcc\n\t"                                                                           \
+  "v_min_f32_dpp %[r], %[r], %[r] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                 \
+  "s_sub_u32 vcc_lo, vcc_lo, %[l0]\n\t"                                                               \
+  "s_subb_u32 vcc_hi, vcc_hi, %[l1]\n\t"
+#define ADMM_PB_DPP(dst, how) "v_min_f32_dpp %[" dst "], %[r], %[r] " how " row_mask:0xf bank_mask:0xf\n\t"
+              // below = (eq - lsb) & ~eq, keep = lt | (le & below) ...
+#define ADMM_PB_MASKS "s_andn2_b64 vcc, vcc, %[E]\n\ts_and_b64 vcc, vcc, %[LE]\n\t"
+#define ADMM_PB_KEEP "s_or_b64 %[LE], vcc, %[LT]\n\t"
+              // ... and both masks into lane ls of their register pairs
+#define ADMM_PB_WRITE "s_bfm_b64 exec, 1, %[ls]\n\tv_mov_b64 %[vk], %[LE]\n\tv_mov_b64 %[ve], %[E]\n\ts_mov_b64 exec, -1\n\t"
+#define ADMM_PB_TAIL "v_med3_f32 %[t], %[M], %[C], %[pad]\n\tv_add_f32_e32 %[Mo], %[th], %[t]"
+#define ADMM_PB_OPERANDS                                                                                                                          \
+  : [c] "=&v"(c), [r] "=&v"(r), [t] "=&v"(t), [C] "=&v"(C1), [Mo] "=&v"(Mnew), [LT] "=&s"(m_lt), [LE] "=&s"(m_le), [E] "=&s"(m_eq),               \
+    [vk] "+v"(vk64), [ve] "+v"(ve64)                                                                                                              \
+  : [M] "v"(Mreg), [wp] "v"(wpot), [pc] "v"(pend_c), [pC] "v"(pend_C1), [pM] "v"(pend_M), [th] "v"(th_own), [pad] "v"(potts_pad),                  \
+    [ls] "s"(pend_ls), [l0] "n"((unsigned)kFieldLsb<KP>), [l1] "n"((unsigned)(kFieldLsb<KP> >> 32))                                               \
+  : "vcc", "scc"
+              if constexpr (KP == 8) {
+                asm(ADMM_PB_HEAD ADMM_PB_DPP("C", "row_half_mirror") ADMM_PB_MASKS ADMM_PB_KEEP ADMM_PB_WRITE ADMM_PB_TAIL ADMM_PB_OPERANDS);
+              } else if constexpr (KP == 16) {
+                asm(ADMM_PB_HEAD ADMM_PB_DPP("r", "row_half_mirror") ADMM_PB_MASKS ADMM_PB_DPP("C", "row_mirror") ADMM_PB_KEEP ADMM_PB_WRITE ADMM_PB_TAIL
+                    ADMM_PB_OPERANDS);
+              } else if constexpr (KP == 32) {
+                // (the lane write sits between the copy and the row swap that reads it: its two wait states)
+                asm(ADMM_PB_HEAD ADMM_PB_DPP("r", "row_half_mirror") ADMM_PB_MASKS ADMM_PB_DPP("r", "row_mirror") ADMM_PB_KEEP
+                    "v_mov_b32 %[t], %[r]\n\t" ADMM_PB_WRITE "v_permlane16_swap_b32 %[r], %[t]\n\tv_min_f32_e32 %[C], %[r], %[t]\n\t" ADMM_PB_TAIL
+                    ADMM_PB_OPERANDS);
+              } else {
+                static_assert(KP == 64, "lanes per chain");
+                asm(ADMM_PB_HEAD ADMM_PB_DPP("r", "row_half_mirror") ADMM_PB_MASKS ADMM_PB_DPP("r", "row_mirror") ADMM_PB_KEEP
+                    "v_mov_b32 %[t], %[r]\n\t" ADMM_PB_WRITE "v_permlane16_swap_b32 %[r], %[t]\n\tv_min_f32_e32 %[r], %[r], %[t]\n\t"
+                    "v_mov_b32 %[t], %[r]\n\ts_nop 1\n\tv_permlane32_swap_b32 %[r], %[t]\n\tv_min_f32_e32 %[C], %[r], %[t]\n\t" ADMM_PB_TAIL
+                    ADMM_PB_OPERANDS);
+              }
+#undef ADMM_PB_HEAD
+#undef ADMM_PB_DPP
+#undef ADMM_PB_MASKS
+#undef ADMM_PB_KEEP
+#undef ADMM_PB_WRITE
+#undef ADMM_PB_TAIL
+#undef ADMM_PB_OPERANDS
+              if constexpr (PCOMP) {
+                if (pend) origin_step(m_eq, m_le);  // of the step before, whose masks these are
+                if (j == 0) origin_block(tb);
+              }
               pend_c = c;
               pend_C1 = C1;
               pend_M = Mreg;

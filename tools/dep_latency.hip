@@ -103,6 +103,62 @@ __global__ void chain_kernel(float *out, unsigned long long *ticks, float seed) 
                    "v_pk_add_f32 %0, %0, %4\n\tv_pk_add_f32 %1, %1, %4\n\tv_pk_add_f32 %2, %2, %4\n\tv_pk_add_f32 %3, %3, %4"
                    : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(sd));
       y0 = p0.x; y1 = p0.y; y2 = p1.x; y3 = p1.y; y4 = p2.x; y5 = p2.y; y6 = p3.x; y7 = p3.y;
+    } else if constexpr (KIND == 18 || KIND == 19) {  // the Potts step with the masks of the step before threaded through it
+      float cc, r, t;
+      unsigned long long m_lt, m_le, m_eq;
+      static unsigned long long vk, ve;
+      float pc = y0, pC = y1, pM = y2;
+      if constexpr (KIND == 18) {
+      asm volatile(
+                   "v_add_f32_e32 %[c], %[M], %[wp]\n\t"
+                   "v_cmp_eq_f32_e32 vcc, %[pc], %[pC]\n\t"
+                   "v_cmp_lt_f32_e64 %[LT], %[pM], %[pC]\n\t"
+                   "v_min_f32_dpp %[r], %[c], %[c] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                   "v_cmp_le_f32_e64 %[LE], %[pM], %[pC]\n\t"
+                   "s_mov_b64 %[E], vcc\n\t"
+                   "v_min_f32_dpp %[r], %[r], %[r] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                   "s_sub_u32 vcc_lo, vcc_lo, 1\n\t"
+                   "s_subb_u32 vcc_hi, vcc_hi, 1\n\t"
+                   "v_min_f32_dpp %[r], %[r], %[r] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                   "s_andn2_b64 vcc, vcc, %[E]\n\t"
+                   "s_and_b64 vcc, vcc, %[LE]\n\t"
+                   "v_min_f32_dpp %[r], %[r], %[r] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                   "s_or_b64 %[LE], vcc, %[LT]\n\t"
+                   "s_bfm_b64 exec, 1, %[ls]\n\t"
+                   "v_mov_b64 %[vk], %[LE]\n\t"
+                   "v_mov_b64 %[ve], %[E]\n\t"
+                   "s_mov_b64 exec, -1\n\t"
+                   "v_mov_b32 %[t], %[r]\n\t"
+                   "s_nop 1\n\t"
+                   "v_permlane16_swap_b32 %[r], %[t]\n\t"
+                   "v_min_f32_e32 %[pC], %[r], %[t]\n\t"
+                   "v_med3_f32 %[t], %[M], %[pC], %[pad]\n\t"
+                   "v_mov_b32 %[pM], %[M]\n\t"
+                   "v_mov_b32 %[pc], %[c]\n\t"
+                   "v_add_f32_e32 %[M], %[th], %[t]"
+                   : [c] "=&v"(cc), [r] "=&v"(r), [t] "=&v"(t), [LT] "=&s"(m_lt), [LE] "=&s"(m_le), [E] "=&s"(m_eq), [vk] "+v"(vk), [ve] "+v"(ve),
+                     [M] "+v"(x), [pc] "+v"(pc), [pC] "+v"(pC), [pM] "+v"(pM)
+                   : [wp] "v"(seed), [th] "v"(y3), [pad] "v"(-__builtin_inff()), [ls] "s"(it & 63)
+                   : "vcc", "scc");
+      } else {  // the vector instructions alone
+      asm volatile("v_add_f32_e32 %[c], %[M], %[wp]\n\t"
+                   "v_min_f32_dpp %[r], %[c], %[c] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                   "s_nop 1\n\t"
+                   "v_min_f32_dpp %[r], %[r], %[r] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                   "s_nop 1\n\t"
+                   "v_min_f32_dpp %[r], %[r], %[r] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                   "s_nop 1\n\t"
+                   "v_min_f32_dpp %[r], %[r], %[r] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                   "v_mov_b32 %[t], %[r]\n\t"
+                   "s_nop 1\n\t"
+                   "v_permlane16_swap_b32 %[r], %[t]\n\t"
+                   "v_min_f32_e32 %[pC], %[r], %[t]\n\t"
+                   "v_med3_f32 %[t], %[M], %[pC], %[pad]\n\t"
+                   "v_add_f32_e32 %[M], %[th], %[t]"
+                   : [c] "=&v"(cc), [r] "=&v"(r), [t] "=&v"(t), [M] "+v"(x), [pC] "+v"(pC)
+                   : [wp] "v"(seed), [th] "v"(y3), [pad] "v"(-__builtin_inff()));
+      }
+      y0 = pc; y1 = pC; y2 = pM;
     } else {  // one full 32-lane minimum as the Potts step does it, then the median and the add that close the step
       float r, t;
       asm volatile("v_add_f32_e32 %0, %2, %3\n\t"
@@ -160,6 +216,8 @@ int main() {
   run<15>("v_add_f32 and s_add_i32 alternating (16 instructions)", 16, d_out, d_t);
   run<16>("v_add_f32, dependent at distance four", 8, d_out, d_t);
   run<17>("v_pk_add_f32, dependent at distance four", 8, d_out, d_t);
+  run<18>("Potts step, masks of the step before threaded through", 1, d_out, d_t);
+  run<19>("Potts step, its chain of vector instructions alone", 1, d_out, d_t);
   run<7>("Potts chain: add, 32-lane minimum, median, add", 1, d_out, d_t);
   hipFree(d_out); hipFree(d_t);
   return 0;
