@@ -344,21 +344,22 @@ void launch_sweep_t(const ChainArgs &a, int blocks, hipStream_t s) {
   hipLaunchKernelGGL((chain_sweep_kernel<KP, NS, sweep_gpb(KP, NS), sweep_minw(KP, NS), DUAL>), dim3(blocks), dim3(kChainBlock), 0, s, a);
 }
 
-// Two wavefronts per half chain (the kernels built with SPLIT): for launches that leave
-// half of the SIMDs without a wavefront (one strip of eight of the 2048 x 2048 grid: 512
-// wavefronts; 0.189 -> 0.178 ms per sweep).  With a wavefront on every SIMD already (one
-// strip of four) the second one only competes: 0.195 -> 0.224 ms.  The gain is small because
-// a lone wavefront's step is bound by the recursion's own dependent instructions, which the
-// shell's used to fill the gaps of.  ADMM_SWEEP_TWOWAVE=0/1 (tuning and test knob) overrides.
-bool twowave_chosen(int KP, int waves) {
-  if (KP != 32) return false;
+// Two wavefronts per half chain (the kernels built with SPLIT), for launches with at most one
+// wavefront per SIMD (one strip of eight or of four of the 2048 x 2048 grid: 512 or 1024
+// wavefronts).  A wavefront alone on its SIMD issues one instruction every 4.8 clock ticks
+// whatever its kind, so halving the instructions per wavefront and step is what shortens the
+// sweep: 0.178 -> 0.116 ms per sweep for a strip of eight, 0.159 -> 0.143 ms for one of four
+// (there the second wavefront shares a SIMD with another chain's); with two wavefronts per SIMD
+// to begin with (a strip of two) it changes nothing.  ADMM_SWEEP_TWOWAVE=0/1 (tuning and test
+// knob) overrides.
+bool twowave_chosen(int KP, int waves, bool trunc = false) {
+  if (KP != 32 && !trunc) return false;
   if (const char *e = getenv("ADMM_SWEEP_TWOWAVE")) return atoi(e) != 0;
   return waves <= 1024;
 }
 template <int KP>
 void launch_sweep_potts_split_t(const ChainArgs &a, int blocks, hipStream_t s, bool lam16, bool lam8) {
-  if (lam8 && getenv("ADMM_SWEEP_GPB16")) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 16, 2, false, true, true, false, true, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
-  else if (lam8) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, false, true, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+  if (lam8) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, false, true, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
   else if (lam16) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, false, false, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
   else hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, false, false, false, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
 }
@@ -372,12 +373,6 @@ void launch_sweep_potts_t(const ChainArgs &a, int blocks, hipStream_t s) {
 template <int KP, bool PCOMP = false>
 void launch_sweep_potts16_t(const ChainArgs &a, int blocks, hipStream_t s, bool lam8) {
   // (operands 16 steps ahead instead of 8: 1 to 2 % slower; 32: spills)
-  if constexpr (KP == 32 && !PCOMP) {
-    if (lam8 && getenv("ADMM_SWEEP_GPB16")) {
-      hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 16, 2, false, true, true, PCOMP, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
-      return;
-    }
-  }
   if (lam8) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, PCOMP, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
   else hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, PCOMP>), dim3(blocks), dim3(kChainBlock), 0, s, a);
 }
@@ -468,6 +463,13 @@ int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
     }
     HIP_TRY(c, hipGetLastError());
     return ADMM_OK;
+  }
+  if (trunc && twowave_chosen(sh.KP, w, true)) {
+    a.mix_blocks = 0;
+    if (c->lam16 && c->lam8) hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, true, false, true, true, 3>), dim3(w / 2), dim3(kChainBlock), 0, s, a);
+    else if (c->lam16) hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, true, false, false, true, 3>), dim3(w / 2), dim3(kChainBlock), 0, s, a);
+    else hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, false, false, false, true, 3>), dim3(w / 2), dim3(kChainBlock), 0, s, a);
+    goto launched;
   }
   if (trunc) {
     if (c->lam16 && c->lam8) hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, true, false, true, false, 3>), dim3(blocks), dim3(kChainBlock), 0, s, a);
@@ -1496,13 +1498,14 @@ int admm_init(admm_ctx *c) {
       for (int dd = 0; dd < std::min(k, 4) && tr; dd++) tr = wt[(size_t)dd] <= wfar;
       // Four chains share a wavefront in that kernel: it takes about half the instructions
       // per chain and step of the general one, which spreads a chain over a whole wavefront,
-      // but on a quarter of the wavefronts.  While those leave SIMDs empty the general kernel
-      // is the faster one (512 x 512: 512 wavefronts, 0.061 against 0.053 ms per sweep;
-      // 1024 x 1024: 1024 wavefronts, 0.114 against 0.185 ms).
+      // but on a quarter of the wavefronts (twice that many up to 1024, see twowave_chosen).
+      // Small grids leave most SIMDs empty either way and the general kernel's shorter step
+      // wins (256 x 256: 0.030 against 0.026 ms per sweep; 384 x 384: 0.039 against 0.042;
+      // 512 x 512: 0.049 against 0.053; 1024 x 1024: 0.104 against 0.158).
       // ADMM_SWEEP_TRUNC=0/1 (tuning and test knob) overrides the choice.
       const long long tw = 2 * (((long long)d.batch * c->st.nrows + 3) / 4) + 2 * (((long long)d.batch * c->st.ncols + 3) / 4);
       const char *et = getenv("ADMM_SWEEP_TRUNC");
-      c->trunc3 = tr && c->KP == 16 && (et ? atoi(et) != 0 : tw >= 640);
+      c->trunc3 = tr && c->KP == 16 && (et ? atoi(et) != 0 : tw >= 384);
     }
     // int16 multiplier counts (the LAM16 kernels): the Potts kernel or the one for truncated
     // tables (the general kernel reads binary32 only), penalty / 2 a power of two well inside
@@ -2474,8 +2477,11 @@ int admm_sweep_kernel_name(admm_ctx *c, char *buf, int len) {
     snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, 1, 8, 4, false, true, %s, %s, %s, %s, 0>", sh.KP, c->lam16 ? "true" : "false",
              (!two && pcomp_chosen(sh.KP, waves)) ? "true" : "false", (c->lam16 && c->lam8) ? "true" : "false", two ? "true" : "false");
   } else if (trunc_chosen(c, sh))
-    snprintf(buf, (size_t)len, "chain_sweep_kernel<16, 1, 8, 4, false, false, %s, false, %s, false, 3>", c->lam16 ? "true" : "false",
-             (c->lam16 && c->lam8) ? "true" : "false");
+  {
+    const int waves = 2 * ((c->d.batch * c->st.nrows + 3) / 4) + 2 * ((c->d.batch * c->st.ncols + 3) / 4);
+    snprintf(buf, (size_t)len, "chain_sweep_kernel<16, 1, 8, 4, false, false, %s, false, %s, %s, 3>", c->lam16 ? "true" : "false",
+             (c->lam16 && c->lam8) ? "true" : "false", twowave_chosen(16, waves, true) ? "true" : "false");
+  }
   else
     snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, %d, %d, %d, false, false, false, false, false, false, 0>", sh.KP, sh.NS, sweep_gpb(sh.KP, sh.NS), sweep_minw(sh.KP, sh.NS));
   return ADMM_OK;

@@ -77,13 +77,22 @@ def _check(R, C, k, un, W, monkeypatch, G=1, iters=4, expect_trunc=True, penalty
     for _ in range(iters):
         o.compute(); o.update()
         ref.append(o.labels().copy())
-    a = _run(R, C, k, un, W, G, iters, "1", monkeypatch, penalty)   # (left to itself the library takes it from 640 wavefronts on)
+    a = _run(R, C, k, un, W, G, iters, "1", monkeypatch, penalty)   # (left to itself the library takes it from 384 wavefronts on)
     assert all(_is_trunc(n) == expect_trunc for n in a["names"]), a["names"]
     if counts is not None and expect_trunc:   # the kernel the run started with (field 6: counts)
         assert all((n.split(",")[6].strip() == "true") == counts for n in a["names"]), a["names"]
     b = _run(R, C, k, un, W, G, iters, "0", monkeypatch, penalty)
     assert not any(_is_trunc(n) for n in b["names"]), b["names"]
-    for name, r in (("default kernel", a), ("general kernel", b)):
+    runs = [("kernel for truncated tables", a), ("general kernel", b)]
+    if expect_trunc:
+        # up to 1024 wavefronts the kernel runs as two wavefronts per half chain (field 9 of the name); the other form too
+        two = a["names"][0].split(",")[9].strip() == "true"
+        monkeypatch.setenv("ADMM_SWEEP_TWOWAVE", "0" if two else "1")
+        a2 = _run(R, C, k, un, W, G, iters, "1", monkeypatch, penalty)
+        monkeypatch.delenv("ADMM_SWEEP_TWOWAVE")
+        assert all(_is_trunc(n) and (n.split(",")[9].strip() == "true") != two for n in a2["names"]), a2["names"]
+        runs.append(("kernel for truncated tables, %s wavefronts per half chain" % ("one" if two else "two"), a2))
+    for name, r in runs:
         for it in range(iters):
             assert np.array_equal(r["labels"][it], ref[it]), "%s: labels, iteration %d" % (name, it + 1)
         assert np.array_equal(r["xrow"], o.xrow) and np.array_equal(r["xcol"], o.xcol), name
@@ -157,10 +166,10 @@ def test_tables_outside_the_form_take_the_general_kernel(what, monkeypatch):
     _check(R, C, k, _unaries(R, C, k, 5, quant=4), W, monkeypatch, expect_trunc=False)
 
 
-@pytest.mark.parametrize("size,chosen", [(512, False), (1024, True)])
+@pytest.mark.parametrize("size,chosen", [(256, False), (512, True)])
 def test_truncated_linear_at_full_size_and_the_default_choice(size, chosen, monkeypatch):
-    """512 x 512 (BASELINE's truncated linear configuration) leaves half of the SIMDs without a
-    wavefront in this kernel and takes the general one unless told otherwise; 1024 x 1024 takes it."""
+    """512 x 512 (the benchmark's truncated linear configuration) takes this kernel; 256 x 256 leaves
+    most SIMDs without a wavefront and takes the general one unless told otherwise."""
     import admm_amd as A
     from oracle import oracle as O
     import os

@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # rows, cols, k, batch, strips (strip 0 of that many is run alone)
-CASES = [(512, 512, 16, 1, 1), (1024, 1024, 16, 1, 1), (2048, 2048, 16, 1, 1), (4096, 4096, 16, 1, 1), (64, 64, 16, 256, 1)]
+CASES = [(128, 128, 16, 1, 1), (256, 256, 16, 1, 1), (384, 384, 16, 1, 1), (512, 512, 16, 1, 1), (1024, 1024, 16, 1, 1), (2048, 2048, 16, 1, 1), (4096, 4096, 16, 1, 1), (64, 64, 16, 256, 1)]
 
 WORKER = r"""
 import sys, time
