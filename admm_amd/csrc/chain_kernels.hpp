@@ -2087,7 +2087,51 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     }
     wave_lds_fence();
     if (ci > 0) fetch_chunk(ci - 1);
-    if (within == 0) {
+    // Whole chunks, 8 or 16 lanes per chain: the walk in three short phases instead of 64
+    // dependent LDS reads by one lane.  (A) every lane walks each of the chunk's eight blocks
+    // of eight steps from its own label as the block's last one - eight independent walks
+    // per lane, their reads overlap - which leaves, per block, the label before the block as
+    // a function of the label at its end; (B) one lane per chain hops over the eight blocks
+    // (8 dependent reads) and leaves every block's last label; (C) lane j of the chain walks
+    // block j (8 dependent reads).  The tables of (A) and the labels of (B) live in the
+    // wavefront's row of s_xo, which the forward pass is done with.
+    constexpr bool PWALK = NS == 1 && (KP == 8 || KP == 16);
+    if (PWALK && n == kChunk) {
+      const uint8_t *bytes = reinterpret_cast<const uint8_t *>(&s_bp[wib][cs][0]);
+      uint8_t *gtab = reinterpret_cast<uint8_t *>(&s_xo[wib][cs][0]);  // [block][label]
+      int *xend = &s_xo[wib][cs][(8 * KP) / 4];                         // [block]
+      int v[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) v[j] = b;
+#pragma unroll
+      for (int st = 7; st >= 0; st--) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int tt = 8 * j + st;
+          v[j] = bytes[(v[j] << 2) + (((tt >> 2) * KP) << 2) + (tt & 3)];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) gtab[j * KP + b] = (uint8_t)v[j];
+      wave_lds_fence();
+      if (within == 0) {
+#pragma unroll
+        for (int j = 7; j >= 0; j--) {
+          xend[j] = cur;
+          cur = gtab[j * KP + cur];  // (the chain's first chunk: the value after block 0 is not used)
+        }
+      }
+      wave_lds_fence();
+      if (within < 8) {
+        int c = xend[within];
+        const int base = within * 2 * KP * 4;  // block `within` starts at step 8 * within: dword 2 * within of every label
+#pragma unroll
+        for (int st = 7; st >= 0; st--) {
+          s_x[wib][cs][8 * within + st] = c;
+          if (st > 0) c = bytes[base + (c << 2) + (((st >> 2) * KP) << 2) + (st & 3)];
+        }
+      }
+    } else if (within == 0) {
       const uint8_t *bytes = reinterpret_cast<const uint8_t *>(&s_bp[wib][cs][0]);
       if (n == kChunk && ci > 0) {
         // whole chunk, not the chain's first: every offset but the label is static
