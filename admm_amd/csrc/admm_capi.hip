@@ -145,6 +145,17 @@ struct admm_ctx {
   label_t *xo_r = nullptr;     // [batch][nrows][cols]   column-chain labels on my rows, row-major: what the row sweep reads
   label_t *xo_c = nullptr;     // [batch][ncols][rows]   row-chain labels on my columns, column-major: what the column sweep reads
   bool one_strip() const { return d.nranks == 1; }
+  // One strip, direct labels: the sweep reads the crossing chains' labels straight from the
+  // array those chains wrote (one byte per step, a grid row or column apart) instead of from a
+  // transposed copy, so admm_update launches nothing.  The sweep of one set must not write
+  // where the other set reads in the same launch, hence two buffers per set: the published one
+  // (what the crossing chains read: the labels as of the last admm_update) and the other, which
+  // the sweep writes; xrow_r / xcolT_c always point at the newest labels.  The transposed copies
+  // xo_r / xo_c are then made only when a kernel other than the sweep asks for them.
+  bool direct_labels = false;
+  label_t *xrow_buf[2] = {nullptr, nullptr}, *xcolT_buf[2] = {nullptr, nullptr};
+  label_t *xrow_pub = nullptr, *xcolT_pub = nullptr;
+  bool xo_stale = false;
   uint8_t *bp_r = nullptr, *bp_c = nullptr;
   float *d_W = nullptr, *d_Wsplit = nullptr, *d_Wt = nullptr;
   float *d_WsplitT = nullptr, *d_WtT = nullptr;  // transposes, for the half chains swept backwards
@@ -161,6 +172,14 @@ struct admm_ctx {
   // gather kernel.
   double *d_chain_lin = nullptr;    // per chain: pairwise energy of its new labels (written by Compute)
   double *d_chain_unary = nullptr;  // per chain: unary energy of the labels the last sweep started from
+  // (both exist twice and every sweep writes the pair the one before it did not, so that sums
+  // over the last sweep's terms can run inside the next sweep's launch)
+  double *d_chain_lin_alt = nullptr, *d_chain_unary_alt = nullptr;
+  // Sums of per-half-chain terms into objective slots that are queued but not launched yet:
+  // they ride along with the next sweep (one spare workgroup of its launch), or are launched
+  // on their own when somebody reads a slot first.
+  struct RedJob { double *dst; const double *part; int n; };
+  std::vector<RedJob> red_q;
   bool lin_valid = false;
   int pending_slot = 0;             // queued objective whose unary term is still to come, or 0
   int swept_slot = 0;               // queued objective whose unary term the last sweep left, unsummed, in d_chain_unary
@@ -178,6 +197,7 @@ struct admm_ctx {
 
   // ---- profiling ----
   bool prof = false;
+  int prof_every = 1, prof_seen = 0;  // every prof_every-th Compute is timed
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   size_t prof_used = 0;
 };
@@ -408,6 +428,26 @@ bool potts_chosen(const admm_ctx *c, SweepShape sh) { return c->potts && sh.KP >
 // (which is the same idea with no neighbours) does not apply.
 bool trunc_chosen(const admm_ctx *c, SweepShape sh) { return c->trunc3 && sh.KP == 16 && !potts_chosen(c, sh); }
 
+// One strip: does the sweep read the crossing chains' labels where those chains wrote them (one
+// byte per step, a grid row or column apart, fetched a chunk of 64 steps ahead), so that
+// admm_update launches nothing?  The strided bytes cost the sweep extra memory requests: free
+// while it is bound by latency or by the vector ALU (512 x 512, k = 16: 19.3 k -> 21.3 k it/s;
+// 64 x 64, k = 4: 36.7 k -> 43.2 k; 256 grids of 256 x 256, k = 8: 2090 -> 2250), 5 % of a sweep
+// that runs at the rate of the memory system (2048 x 2048, k = 32 Potts with four wavefronts per
+// SIMD: 0.350 -> 0.369 ms, more than the 10 us the two transpositions take), which therefore
+// keeps the transposed copies.  ADMM_DIRECT_LABELS=0/1 (tuning and test knob) overrides.
+bool direct_labels_chosen(const admm_ctx *c) {
+  if (c->d.nranks != 1) return false;
+  if (const char *e = getenv("ADMM_DIRECT_LABELS")) return atoi(e) != 0;
+  const long long nr = (long long)c->d.batch * c->st.nrows, nc = (long long)c->d.batch * c->st.ncols;
+  SweepShape sh = pick_shape(c->KP, nr + nc);
+  const bool potts = potts_chosen(c, sh);
+  if (potts || trunc_chosen(c, sh)) sh.NS = 1;
+  const int CPW = 64 / (sh.KP * sh.NS);
+  const long long waves = 2 * ((nr + CPW - 1) / CPW) + 2 * ((nc + CPW - 1) / CPW);
+  return !(potts && sh.KP >= 32 && waves >= 4096);
+}
+
 template <bool DUAL>
 int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
   const bool potts = !DUAL && potts_chosen(c, sh);
@@ -435,9 +475,20 @@ int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
     }
   }
   hipStream_t s = c->stream;
+  // A batch of grids: every die works on whole grids, so that the two reads of a node's
+  // unaries (by its row chain and by its column chain) meet in that die's cache when they
+  // are close in time (256 grids of 256 x 256, k = 8: 0.448 -> 0.437 ms per sweep).  One large
+  // grid loses by it (2048 x 2048, k = 32: 0.350 -> 0.362 ms).  ADMM_SWEEP_XCD=0/1 overrides.
+  a.xcd_remap = c->d.batch >= 8;
+  if (const char *ex = getenv("ADMM_SWEEP_XCD")) a.xcd_remap = atoi(ex) != 0;
+  // queued sums ride along as one more workgroup, behind the sweep's own
+  const int w_split = w / 2 + (a.red_jobs > 0 ? 1 : 0);
+  a.red_block = blocks;
+  if (a.red_jobs > 0) blocks++;
   if (potts && twowave_chosen(sh.KP, w)) {
     a.mix_blocks = 0;
-    launch_sweep_potts_split_t<32>(a, w / 2, s, c->lam16, c->lam16 && c->lam8);  // a workgroup per group of chains
+    a.red_block = w / 2;
+    launch_sweep_potts_split_t<32>(a, w_split, s, c->lam16, c->lam16 && c->lam8);  // a workgroup per group of chains
     HIP_TRY(c, hipGetLastError());
     return ADMM_OK;
   }
@@ -466,9 +517,10 @@ int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
   }
   if (trunc && twowave_chosen(sh.KP, w, true)) {
     a.mix_blocks = 0;
-    if (c->lam16 && c->lam8) hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, true, false, true, true, 3>), dim3(w / 2), dim3(kChainBlock), 0, s, a);
-    else if (c->lam16) hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, true, false, false, true, 3>), dim3(w / 2), dim3(kChainBlock), 0, s, a);
-    else hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, false, false, false, true, 3>), dim3(w / 2), dim3(kChainBlock), 0, s, a);
+    a.red_block = w / 2;
+    if (c->lam16 && c->lam8) hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, true, false, true, true, 3>), dim3(w_split), dim3(kChainBlock), 0, s, a);
+    else if (c->lam16) hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, true, false, false, true, 3>), dim3(w_split), dim3(kChainBlock), 0, s, a);
+    else hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, false, false, false, true, 3>), dim3(w_split), dim3(kChainBlock), 0, s, a);
     goto launched;
   }
   if (trunc) {
@@ -494,9 +546,10 @@ launched:
 
 void fill_seg_rows(const admm_ctx *c, ChainSeg &s, bool dual) {
   const admm_desc &d = c->d;
-  s.theta = c->th_r; s.lam = c->lam_r; s.x = c->xrow_r;
+  s.theta = c->th_r; s.lam = c->lam_r; s.x = c->xrow_r; s.xin = c->xrow_r;
   s.lam_out = dual ? nullptr : (c->lam_shared() ? c->lam_c : c->lam_r);
   s.lam_sign = 0; s.xo = c->xo_r; s.bp = c->bp_r;
+  s.xo_gstride = (long long)std::max(1, c->st.nrows) * d.cols; s.xo_cstride = d.cols; s.xo_sstride = 1;
   s.chain_min = dual ? c->d_chain_min : nullptr;
   s.chain_lin = c->d_chain_lin;
   s.chain_unary = c->d_chain_unary;
@@ -510,9 +563,10 @@ void fill_seg_rows(const admm_ctx *c, ChainSeg &s, bool dual) {
 
 void fill_seg_cols(const admm_ctx *c, ChainSeg &s, bool dual) {
   const admm_desc &d = c->d;
-  s.theta = c->th_c; s.lam = c->lam_shared() ? c->lam_r : c->lam_c; s.x = c->xcolT_c;
+  s.theta = c->th_c; s.lam = c->lam_shared() ? c->lam_r : c->lam_c; s.x = c->xcolT_c; s.xin = c->xcolT_c;
   s.lam_out = (dual || c->lam_shared()) ? nullptr : c->lam_c;
   s.lam_sign = c->lam_shared() ? 0x80000000u : 0u; s.xo = c->xo_c; s.bp = c->bp_c;
+  s.xo_gstride = (long long)std::max(1, c->st.ncols) * d.rows; s.xo_cstride = d.rows; s.xo_sstride = 1;
   s.chain_min = dual ? c->d_chain_min + (long long)d.batch * c->st.nrows : nullptr;
   s.chain_lin = c->d_chain_lin + 2LL * d.batch * c->st.nrows;
   s.chain_unary = c->d_chain_unary + 2LL * d.batch * c->st.nrows;
@@ -525,6 +579,10 @@ void fill_seg_cols(const admm_ctx *c, ChainSeg &s, bool dual) {
 }
 
 int chain_sweep_launch(admm_ctx *c, bool dual);
+int settle_swept_now(admm_ctx *c);
+int flush_red(admm_ctx *c);
+bool red_deferred(const admm_ctx *c);
+inline int chain_terms(const admm_ctx *c) { return 2 * c->d.batch * (c->st.nrows + c->st.ncols); }  // one per half chain
 
 // counts -> binary32 multipliers: out[i] = in[i] * (penalty / 2), exact
 template <typename TC>
@@ -692,6 +750,16 @@ int lam8_cover(admm_ctx *c, int s) {
   return ADMM_OK;
 }
 
+// After a sweep that was queued without error: its outputs become the current ones.
+void sweep_outputs_current(admm_ctx *c, const ChainArgs &a) {
+  std::swap(c->d_chain_lin, c->d_chain_lin_alt);
+  std::swap(c->d_chain_unary, c->d_chain_unary_alt);
+  if (c->direct_labels) {
+    c->xrow_r = a.seg[0].x;
+    c->xcolT_c = a.seg[1].x;
+  }
+}
+
 int chain_sweep(admm_ctx *c, bool dual) {
   if (!dual && c->lam8) {
     const int rc = lam8_cover(c, c->lam16_sweeps);
@@ -737,6 +805,37 @@ int chain_sweep_launch(admm_ctx *c, bool dual) {
   a.WtT = dual ? c->d_WsplitT : c->d_WtT;
   a.WsplitT = c->d_WsplitT;
   SweepShape sh = pick_shape(c->KP, (long long)a.seg[0].nchains + a.seg[1].nchains);
+  if (!dual) {
+    // this sweep's per-half-chain terms go where the last sweep's are not
+    const long long off = 2LL * c->d.batch * c->st.nrows;
+    a.seg[0].chain_lin = c->d_chain_lin_alt; a.seg[0].chain_unary = c->d_chain_unary_alt;
+    a.seg[1].chain_lin = c->d_chain_lin_alt + off; a.seg[1].chain_unary = c->d_chain_unary_alt + off;
+    if (c->direct_labels) {
+      // the crossing chains' labels as of the last admm_update, read where those chains wrote them
+      ChainSeg &r = a.seg[0], &cc = a.seg[1];
+      r.x = c->xrow_r == c->xrow_pub ? c->xrow_buf[c->xrow_r == c->xrow_buf[0] ? 1 : 0] : c->xrow_r;
+      cc.x = c->xcolT_c == c->xcolT_pub ? c->xcolT_buf[c->xcolT_c == c->xcolT_buf[0] ? 1 : 0] : c->xcolT_c;
+      r.xo = c->xcolT_pub; r.xo_cstride = 1; r.xo_sstride = r.cpg;
+      cc.xo = c->xrow_pub; cc.xo_cstride = 1; cc.xo_sstride = cc.cpg;
+    }
+    // queued sums over the last sweep's terms: one more workgroup of this launch
+    if ((long long)a.seg[0].nchains + a.seg[1].nchains == 0) {
+      const int rcq = flush_red(c);
+      if (rcq) return rcq;
+    }
+    if (c->swept_slot && c->red_q.size() < 2 && red_deferred(c)) {
+      c->red_q.push_back({c->d_obj_slots + 2 * (size_t)c->swept_slot, c->d_chain_unary, chain_terms(c)});
+      c->swept_slot = 0;
+    }
+    // (unary terms of an earlier sweep that nobody has summed and that cannot ride along: now)
+    if (c->swept_slot) {
+      const int rcs = settle_swept_now(c);
+      if (rcs) return rcs;
+    }
+    a.red_jobs = (int)c->red_q.size();
+    for (int j = 0; j < a.red_jobs; j++) { a.red_dst[j] = c->red_q[j].dst; a.red_part[j] = c->red_q[j].part; a.red_n[j] = c->red_q[j].n; }
+    c->red_q.clear();
+  }
   if (dual && c->lam16) {
     // the dual evaluation reads binary32 multipliers
     const float *fr = nullptr, *fc = nullptr;
@@ -823,18 +922,24 @@ int chain_sweep_launch(admm_ctx *c, bool dual) {
         fprintf(stderr, "\n");
       }
     }
+    sweep_outputs_current(c, a);
     return ADMM_OK;
   }
+  int rc;
   if (getenv("ADMM_SWEEP_SPLIT")) {  // diagnostic: one launch per set of chains
     ChainArgs b = a;
-    a.nseg = 1;
-    int rc = dual ? launch_sweep<true>(c, a, sh) : launch_sweep<false>(c, a, sh);
-    if (rc) return rc;
     b.nseg = 1;
     b.seg[0] = b.seg[1];
-    return dual ? launch_sweep<true>(c, b, sh) : launch_sweep<false>(c, b, sh);
+    b.red_jobs = 0;  // (the queued sums went with the first launch)
+    ChainArgs a1 = a;
+    a1.nseg = 1;
+    rc = dual ? launch_sweep<true>(c, a1, sh) : launch_sweep<false>(c, a1, sh);
+    if (!rc) rc = dual ? launch_sweep<true>(c, b, sh) : launch_sweep<false>(c, b, sh);
+  } else {
+    rc = dual ? launch_sweep<true>(c, a, sh) : launch_sweep<false>(c, a, sh);
   }
-  return dual ? launch_sweep<true>(c, a, sh) : launch_sweep<false>(c, a, sh);
+  if (!rc && !dual) sweep_outputs_current(c, a);
+  return rc;
 }
 
 template <typename TB>
@@ -1165,7 +1270,14 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
         (rc = dev_alloc(c, &c->d_WtT, k * k)) ||
         (rc = dev_alloc(c, &c->d_chain_min, B * ((size_t)c->st.nrows + c->st.ncols))) ||
         (rc = dev_alloc(c, &c->d_chain_lin, 2 * B * ((size_t)c->st.nrows + c->st.ncols))) ||
-        (rc = dev_alloc(c, &c->d_chain_unary, 2 * B * ((size_t)c->st.nrows + c->st.ncols))))
+        (rc = dev_alloc(c, &c->d_chain_unary, 2 * B * ((size_t)c->st.nrows + c->st.ncols))) ||
+        (rc = dev_alloc(c, &c->d_chain_lin_alt, 2 * B * ((size_t)c->st.nrows + c->st.ncols))) ||
+        (rc = dev_alloc(c, &c->d_chain_unary_alt, 2 * B * ((size_t)c->st.nrows + c->st.ncols))))
+      return bail(rc);
+    // (second label buffers: one strip may run with direct labels, which admm_init decides)
+    c->xrow_buf[0] = c->xrow_r;
+    c->xcolT_buf[0] = c->xcolT_c;
+    if (d.nranks == 1 && ((rc = dev_alloc(c, &c->xrow_buf[1], nrow_nodes)) || (rc = dev_alloc(c, &c->xcolT_buf[1], ncol_nodes))))
       return bail(rc);
     // [slack | data | slack]: the pointers the rest of the code sees are the data's
     HIP_TRY_BAIL(hipMemsetAsync(c->th_r, 0, sizeof(float) * (nrow_nodes * k + 2 * slack), c->stream));
@@ -1464,6 +1576,14 @@ int admm_init(admm_ctx *c) {
     HIP_TRY(c, hipMemsetAsync(c->lam_r, 0, sizeof(float) * nrow * k, s));
     HIP_TRY(c, hipMemsetAsync(c->lam_c, 0, sizeof(float) * ncol * k, s));
     // -1 in every label, whatever its width
+    c->xrow_r = c->xrow_pub = c->xrow_buf[0];
+    c->xcolT_c = c->xcolT_pub = c->xcolT_buf[0];
+    c->xo_stale = false;
+    c->red_q.clear();
+    if (d.nranks == 1) {
+      if (nrow > 0) HIP_TRY(c, hipMemsetAsync(c->xrow_buf[1], 0xFF, sizeof(label_t) * nrow, s));
+      if (ncol > 0) HIP_TRY(c, hipMemsetAsync(c->xcolT_buf[1], 0xFF, sizeof(label_t) * ncol, s));
+    }
     if (nrow > 0) {
       HIP_TRY(c, hipMemsetAsync(c->xrow_r, 0xFF, sizeof(label_t) * nrow, s));
       HIP_TRY(c, hipMemsetAsync(c->xo_r, 0xFF, sizeof(label_t) * nrow, s));
@@ -1534,6 +1654,7 @@ int admm_init(admm_ctx *c) {
       }
     }
   }
+  if (is_chain(c)) c->direct_labels = direct_labels_chosen(c);
   HIP_TRY(c, hipStreamSynchronize(s));
   c->inited = true;
   if (is_chain(c)) c->theta_scaled = true;
@@ -1546,7 +1667,8 @@ int admm_compute(admm_ctx *c) {
   if (rc) return rc;
   if (!c->inited) return fail(c, ADMM_E_STATE, "admm_compute before admm_init");
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (c->prof) {
+  const bool timed = c->prof && (c->prof_seen++ % c->prof_every) == 0;
+  if (timed) {
     if (c->prof_used == c->prof_events.size()) {
       hipEvent_t a, b;
       HIP_TRY(c, hipEventCreate(&a));
@@ -1558,9 +1680,8 @@ int admm_compute(admm_ctx *c) {
     c->prof_used++;
     HIP_TRY(c, hipEventRecord(e0, c->stream));
   }
-  // per-chain unary terms of an earlier sweep that nobody has summed yet: the
-  // sweep below overwrites them
-  if (is_chain(c) && (rc = settle_swept(c))) return rc;
+  // (per-chain unary terms of an earlier sweep that nobody has summed yet are summed by a
+  // spare workgroup of this sweep's launch, or by a launch of their own just before it)
   rc = is_chain(c) ? chain_sweep(c, false) : edge_compute(c);
   if (rc) return rc;
   if (is_chain(c) && c->pending_slot) {
@@ -1571,7 +1692,7 @@ int admm_compute(admm_ctx *c) {
     c->pending_slot = 0;
   }
   c->lin_valid = true;
-  if (c->prof) HIP_TRY(c, hipEventRecord(e1, c->stream));
+  if (timed) HIP_TRY(c, hipEventRecord(e1, c->stream));
   return ADMM_OK;
 }
 
@@ -1936,9 +2057,25 @@ int admm_update(admm_ctx *c) {
   // (Grid.cpp:163-181 with one-hot marginals); the sweep evaluates it from
   // them, so Update only lays each set of labels out along the crossing chains.
   // [cols][nrows] -> [nrows][cols] and [rows][ncols] -> [ncols][rows]
+  if (c->direct_labels) {
+    // the newest labels become the ones the crossing chains read; nothing to launch
+    c->xrow_pub = c->xrow_r;
+    c->xcolT_pub = c->xcolT_c;
+    c->xo_stale = true;
+    return ADMM_OK;
+  }
   if (c->one_strip())
     return transpose_labels2<label_t>(c, c->xo_r, c->xcolT_c, d.cols, c->st.nrows, c->xo_c, c->xrow_r, d.rows, c->st.ncols);
   return transpose_labels2<int>(c, c->xo_r, c->xcolT_r, d.cols, c->st.nrows, c->xo_c, c->xrow_c, d.rows, c->st.ncols);
+}
+
+// Direct labels: the transposed copies (the published labels laid out along the crossing
+// chains), for the kernels that read them; made when first asked for after an admm_update.
+static int ensure_xo(admm_ctx *c) {
+  if (!c->direct_labels || !c->xo_stale) return ADMM_OK;
+  c->xo_stale = false;
+  const admm_desc &d = c->d;
+  return transpose_labels2<label_t>(c, c->xo_r, c->xcolT_pub, d.cols, c->st.nrows, c->xo_c, c->xrow_pub, d.rows, c->st.ncols);
 }
 
 namespace {
@@ -2035,13 +2172,32 @@ int launch_reduce2(admm_ctx *c, Reduce2Args a, int jobs) {
   HIP_TRY(c, hipGetLastError());
   return ADMM_OK;
 }
+
+// Sums of objective terms may wait for the next sweep's launch when one workgroup can do them
+// in the time a sweep takes anyway (a batch of many grids has megabytes of terms: two stages of
+// their own).  ADMM_DEFER_SUMS=0 (test knob): every sum is launched where it is queued.
+bool red_deferred(const admm_ctx *c) {
+  const char *e = getenv("ADMM_DEFER_SUMS");
+  return !(e && atoi(e) == 0) && chain_terms(c) <= 64 * 1024;
+}
+
+// Launches the queued sums now.
+int flush_red(admm_ctx *c) {
+  if (c->red_q.empty()) return ADMM_OK;
+  Reduce2Args a{};
+  const int jobs = (int)c->red_q.size();
+  for (int j = 0; j < jobs; j++) { a.dst[j] = c->red_q[j].dst; a.part[j] = c->red_q[j].part; a.n[j] = c->red_q[j].n; }
+  c->red_q.clear();
+  return launch_reduce2(c, a, jobs);
+}
 }  // namespace
 
 // Queues the chain objective kernels; dst (device, 2 doubles) receives the
 // primal and the linear sums of this strip, not yet scaled by rho.
 static int chain_obj_enqueue(admm_ctx *c, double *dst) {
   hipStream_t s = c->stream;
-  int pass = 0;
+  int pass = ensure_xo(c);
+  if (pass) return pass;
   for (int seg = 0; seg < 2; seg++) {
     ChainSeg sg{};
     if (seg == 0) fill_seg_rows(c, sg, false); else fill_seg_cols(c, sg, false);
@@ -2076,15 +2232,22 @@ static int chain_obj_partials(admm_ctx *c, double *primal, double *linear) {
 // slot[1] = pairwise term; the last sweep left it per half chain in
 // d_chain_lin.  The same launch sums the unary terms that sweep left in
 // d_chain_unary into the slot they belong to (swept_slot), if any.
-static int chain_pairwise_enqueue(admm_ctx *c, double *slot) {
+// defer: the sums may wait for the next sweep's launch (a read of the slot launches them).
+static int chain_pairwise_enqueue(admm_ctx *c, double *slot, bool defer = false) {
+  int rc = flush_red(c);  // sums queued for an earlier solve whose sweep never came
+  if (rc) return rc;
   Reduce2Args a{};
-  const int n = 2 * c->d.batch * (c->st.nrows + c->st.ncols);  // one term per half chain
+  const int n = chain_terms(c);
   a.dst[0] = slot + 1; a.part[0] = c->d_chain_lin; a.n[0] = n;
   int jobs = 1;
   if (c->swept_slot) {
     a.dst[1] = c->d_obj_slots + 2 * (size_t)c->swept_slot; a.part[1] = c->d_chain_unary; a.n[1] = n;
     c->swept_slot = 0;
     jobs = 2;
+  }
+  if (defer && red_deferred(c)) {
+    for (int j = 0; j < jobs; j++) c->red_q.push_back({a.dst[j], a.part[j], a.n[j]});
+    return ADMM_OK;
   }
   return launch_reduce2(c, a, jobs);
 }
@@ -2094,10 +2257,13 @@ static int settle_swept(admm_ctx *c) {
   if (!c->swept_slot) return ADMM_OK;
   Reduce2Args a{};
   a.dst[0] = c->d_obj_slots + 2 * (size_t)c->swept_slot; a.part[0] = c->d_chain_unary;
-  a.n[0] = 2 * c->d.batch * (c->st.nrows + c->st.ncols);
+  a.n[0] = chain_terms(c);
   c->swept_slot = 0;
   return launch_reduce2(c, a, 1);
 }
+namespace {
+int settle_swept_now(admm_ctx *c) { return settle_swept(c); }
+}  // namespace
 
 // slot[0] = unary term of the current labels, gathered now.
 static int chain_unary_gather(admm_ctx *c, double *slot) {
@@ -2123,8 +2289,9 @@ static int chain_unary_gather(admm_ctx *c, double *slot) {
 // run before anything changes the labels or the unaries.
 static int flush_gather(admm_ctx *c);
 static int flush_pending(admm_ctx *c) {
-  int rc = settle_swept(c);
+  int rc = flush_red(c);
   if (rc) return rc;
+  if ((rc = settle_swept(c))) return rc;
   return flush_gather(c);
 }
 static int flush_gather(admm_ctx *c) {
@@ -2192,7 +2359,7 @@ int admm_objective_enqueue(admm_ctx *c, int slot) {
   if (slot < 1 || slot >= c->n_obj_slots) return fail(c, ADMM_E_ARG, "slot must be in [1, %d)", c->n_obj_slots);
   if (!c->lin_valid) return fail(c, ADMM_E_STATE, "admm_objective_enqueue needs a preceding admm_compute");
   if ((rc = flush_gather(c))) return rc;  // two requests for the same solve
-  if ((rc = chain_pairwise_enqueue(c, c->d_obj_slots + 2 * (size_t)slot))) return rc;
+  if ((rc = chain_pairwise_enqueue(c, c->d_obj_slots + 2 * (size_t)slot, true))) return rc;
   c->pending_slot = slot;  // the next sweep (or a read before it) supplies the unary term
   return ADMM_OK;
 }
@@ -2202,6 +2369,7 @@ int admm_objective_read(admm_ctx *c, int slot, int n, double *linear) {
   if (rc) return rc;
   if (!is_chain(c)) return fail(c, ADMM_E_STATE, "queued objectives are a chain-solver feature");
   if (slot < 1 || n < 0 || slot + n > c->n_obj_slots) return fail(c, ADMM_E_ARG, "slot range out of bounds");
+  if ((rc = flush_red(c))) return rc;
   if (c->swept_slot >= slot && c->swept_slot < slot + n && (rc = settle_swept(c))) return rc;
   if (c->pending_slot >= slot && c->pending_slot < slot + n && (rc = flush_pending(c))) return rc;
   std::vector<double> h(2 * (size_t)n);
@@ -2442,7 +2610,9 @@ int admm_profile_reset(admm_ctx *c, int enable) {
   int rc = check_ctx(c);
   if (rc) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  c->prof = enable != 0;
+  c->prof = enable > 0;
+  c->prof_every = std::max(1, enable);
+  c->prof_seen = 0;
   c->prof_used = 0;
   return ADMM_OK;
 }

@@ -56,8 +56,14 @@ struct ChainSeg {
                        // column multipliers are the row ones negated, bit for bit; on one device the
                        // column chains read the row chains' array and store nothing, and the row chains
                        // write into a second buffer that becomes current after the sweep.
-  label_t *x;          // [nchains][T] labels of these chains (-1 before the first solve)
-  const label_t *xo;   // [nchains][T] labels the crossing chains gave the same nodes
+  label_t *x;          // [nchains][T] labels of these chains as the sweep writes them ...
+  const label_t *xin;  // ... and the ones it starts from (-1 before the first solve); may be x itself
+  const label_t *xo;   // labels the crossing chains gave the same nodes: node p of chain c at
+                       //   (c / cpg) * xo_gstride + (c % cpg) * xo_cstride + p * xo_sstride.
+                       // Either laid out along these chains ([nchains][T]: xo_cstride = T, xo_sstride = 1,
+                       // what Update's transposition leaves), or the crossing chains' own array as they
+                       // wrote it ([T][cpg] per grid: xo_cstride = 1, xo_sstride = cpg), read with a stride.
+  long long xo_gstride, xo_cstride, xo_sstride;
   uint8_t *bp;         // [nchains][2][half length padded to 64][KP] back-pointer scratch
   float *chain_min;    // [nchains] (dual evaluation only)
   double *chain_lin;   // [nchains][2] pairwise energy of the new labels per half chain: sum of (W / rho)[x_t][x_t+1]
@@ -86,6 +92,18 @@ struct ChainArgs {
   // out in; the workgroups after them hold two pairs of seg[mix_big], the set
   // that has pairs left over.  0: workgroups are filled set after set.
   int mix_blocks, mix_big;
+  // Sums of per-half-chain objective terms an earlier sweep left (up to two arrays of
+  // binary64 terms, each into one binary64 word), done by workgroup red_block of this
+  // launch, which then takes no part in the sweep.  red_jobs = 0: none.
+  double *red_dst[2];
+  const double *red_part[2];
+  int red_n[2];
+  int red_jobs, red_block;  // red_block is also the number of workgroups that sweep
+  // Workgroups are handed to the eight dies in turn.  xcd_remap: workgroup b works on the
+  // chains of workgroup (b % 8) * (n / 8) + b / 8 instead, so that every die holds a contiguous
+  // range of each set's chains (chains that lie side by side read the same cache lines of the
+  // crossing chains' labels, and every die has a cache of its own).
+  int xcd_remap;
 };
 
 constexpr int kChainBlock = 256;  // two pairs of wavefronts per workgroup (a pair = the two halves of the same chains)
@@ -240,6 +258,40 @@ __device__ __forceinline__ float chain_lanes_min(float x) {
   return r;
 }
 
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+// dst[0] = sum of part[0 .. n), by one workgroup of 256 threads, in the association of a
+// workgroup of 1024 threads (thread t: four running sums over part[t + 1024 j], j = 0 .. 3
+// modulo 4, their pairwise sum, a butterfly over the 64 lanes of its wavefront, then the 16
+// wavefronts in order): wavefront r stands in for the wavefronts r, r + 4, r + 8, r + 12 of
+// that workgroup, so the result has the same bits whichever launch computes it.
+__device__ __forceinline__ void sum_terms_1024(double *__restrict__ dst, const double *__restrict__ part, const int n, double *s_red) {
+  const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+#pragma unroll 1
+  for (int v = 0; v < 4; v++) {
+    const int w = r + 4 * v;  // the wavefront stood in for
+    double l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0;
+    int i = w * 64 + lane;
+    for (; i + 3 * 1024 < n; i += 4 * 1024) {
+      l0 += part[i]; l1 += part[i + 1024]; l2 += part[i + 2048]; l3 += part[i + 3072];
+    }
+    for (; i < n; i += 1024) l0 += part[i];
+    const double l = wave_sum((l0 + l1) + (l2 + l3));
+    if (lane == 0) s_red[w] = l;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; w++) t += s_red[w];
+    dst[0] = t;
+  }
+  __syncthreads();
+}
+
 // Lowest bit of every W-bit field of a 64-bit lane mask.
 template <int W>
 constexpr unsigned long long kFieldLsb = W >= 64 ? 1ull : (~0ull / ((1ull << (W & 63)) - 1));
@@ -339,19 +391,30 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // blocks of GPB load groups per half chain (written, waiting, being read)
   __shared__ float s_ring[SPLIT ? 2 : 1][SPLIT ? 3 * GPB : 1][64];
 
+  if (args.red_jobs > 0 && (int)blockIdx.x == args.red_block) {
+    // the spare workgroup: sums an earlier sweep's objective terms (see ChainArgs)
+    __shared__ double s_red[16];
+    for (int j = 0; j < args.red_jobs; j++) sum_terms_1024(args.red_dst[j], args.red_part[j], args.red_n[j], s_red);
+    return;
+  }
   const int lane = threadIdx.x & 63;
   // the wavefront index is the same in all 64 lanes: keep it (and what
   // derives from it) in scalar registers
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int wave = blockIdx.x * WPB + wib;
+  int blk_id = blockIdx.x;
+  if (args.xcd_remap) {
+    const int per = args.red_block >> 3;
+    if (blk_id < (per << 3)) blk_id = (blk_id & 7) * per + (blk_id >> 3);
+  }
+  int wave = blk_id * WPB + wib;
   // SPLIT: a workgroup holds the two halves of one group of chains, two wavefronts each
   // (role 0: recursion, role 1: shell); the host fills workgroups set after set
   const int role = SPLIT ? (wib & 1) : 0;
-  if constexpr (SPLIT) wave = blockIdx.x * 2 + (wib >> 1);
+  if constexpr (SPLIT) wave = blk_id * 2 + (wib >> 1);
   int si;
   if (!SPLIT && args.mix_blocks > 0) {
     static_assert(WPB == 4, "a workgroup is two pairs of wavefronts");
-    const int blk = blockIdx.x;
+    const int blk = blk_id;
     int wl;
     if (blk < args.mix_blocks) {
       si = wib >> 1;
@@ -568,7 +631,12 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   };
   // labels of the half in sweep order: xchain[xdir * step]
   label_t *xchain = sg.x + (long long)chain * Tfull + (rev ? Tfull - 1 : 0);
-  const label_t *xochain = DUAL ? nullptr : sg.xo + (long long)chain * Tfull + (rev ? Tfull - 1 : 0);
+  const label_t *xinchain = DUAL ? nullptr : sg.xin + (long long)chain * Tfull + (rev ? Tfull - 1 : 0);
+  // ... and the crossing chains' labels of the same nodes: xochain[xostep * step]
+  const long long xostep = (long long)xdir * sg.xo_sstride;
+  const label_t *xochain = DUAL ? nullptr
+                                : sg.xo + (long long)(chain / sg.cpg) * sg.xo_gstride + (long long)(chain % sg.cpg) * sg.xo_cstride +
+                                      (rev ? (long long)(Tfull - 1) * sg.xo_sstride : 0);
   const int Tpad = (T + kChunk - 1) / kChunk * kChunk;
   const int TpadH = (Lhalf + kChunk - 1) / kChunk * kChunk;  // scratch per half chain, in steps
   uint32_t *bpchain = DUAL ? nullptr : reinterpret_cast<uint32_t *>(sg.bp) + ((long long)chain * 2 + rev) * (TpadH / 4) * KP;
@@ -608,8 +676,8 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     for (int q = 0; q < NXL; q++) {
       const int i = within + q * LPC;
       const bool ok = i < kChunk && at + i < T;
-      xnext[q] = ok ? xchain[xdir * (at + i)] : -1;
-      xonext[q] = ok ? xochain[xdir * (at + i)] : -1;
+      xnext[q] = ok ? xinchain[xdir * (at + i)] : -1;
+      xonext[q] = ok ? xochain[xostep * (at + i)] : -1;
     }
   };
   auto labels_to_lds = [&]() {
@@ -624,8 +692,8 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   };
   if (!DUAL && (!SPLIT || role == 1)) {
     for (int i = within; i < kChunk; i += LPC) {
-      s_x[wib][cs][i] = (i < T) ? xchain[xdir * i] : -1;
-      s_xo[wib][cs][i] = (i < T) ? xochain[xdir * i] : -1;
+      s_x[wib][cs][i] = (i < T) ? xinchain[xdir * i] : -1;
+      s_xo[wib][cs][i] = (i < T) ? xochain[xostep * i] : -1;
     }
   }
 
@@ -1239,8 +1307,8 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       } else {
         for (int i = within; i < kChunk; i += LPC) {
           const bool ok = t0 + kChunk + i < T;
-          s_x[wib][cs][i] = ok ? xchain[xdir * (t0 + kChunk + i)] : -1;
-          s_xo[wib][cs][i] = ok ? xochain[xdir * (t0 + kChunk + i)] : -1;
+          s_x[wib][cs][i] = ok ? xinchain[xdir * (t0 + kChunk + i)] : -1;
+          s_xo[wib][cs][i] = ok ? xochain[xostep * (t0 + kChunk + i)] : -1;
         }
       }
       wave_lds_fence();
@@ -1285,8 +1353,8 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
           } else {
             for (int i = within; i < kChunk; i += LPC) {
               const bool ok = t0 + kChunk + i < T;
-              s_x[wib][cs][i] = ok ? xchain[xdir * (t0 + kChunk + i)] : -1;
-              s_xo[wib][cs][i] = ok ? xochain[xdir * (t0 + kChunk + i)] : -1;
+              s_x[wib][cs][i] = ok ? xinchain[xdir * (t0 + kChunk + i)] : -1;
+              s_xo[wib][cs][i] = ok ? xochain[xostep * (t0 + kChunk + i)] : -1;
             }
           }
           wave_lds_fence();
@@ -2249,12 +2317,6 @@ __device__ __forceinline__ int chain_decode(int xr, int xc) {
   // argmax of the consensus, lowest index on ties
   if (xr < 0 || xc < 0) return 0;
   return xr < xc ? xr : xc;
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-  return v;
 }
 
 // Objective terms of one set of chains, one thread per node, on chain-major

@@ -389,7 +389,8 @@ class Grid:
         return out
 
     def ProfileReset(self, enable=True):
-        self._ck(lib.admm_profile_reset(self._h, 1 if enable else 0))
+        """enable: False / True, or n > 1 to time every n-th Compute only."""
+        self._ck(lib.admm_profile_reset(self._h, int(enable)))
 
     def ProfileRead(self):
         ms, n = C.c_double(), C.c_int()

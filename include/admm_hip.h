@@ -237,7 +237,10 @@ int admm_grid_edges(int rows, int cols, int32_t *edge_list);
 
 /* Device-side timing of the solver kernels: average duration in milliseconds
  * of the Compute launches since the last reset, measured with HIP events on
- * the context's stream, and how many launches that covers. */
+ * the context's stream, and how many launches that covers.  enable = 0: off;
+ * 1: every launch is timed; n > 1: every n-th launch (two event records around
+ * a launch cost several microseconds of stream time, which a short iteration
+ * feels; a sample of the launches gives the same average). */
 int admm_profile_reset(admm_ctx *ctx, int enable);
 int admm_profile_read(admm_ctx *ctx, double *compute_ms_avg, int *launches);
 
