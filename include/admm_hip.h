@@ -139,7 +139,12 @@ int admm_communicate_group(admm_ctx **ctxs, int n);
 int admm_exchange_counts(admm_ctx *ctx, int64_t *send_counts, int64_t *recv_counts);
 int admm_exchange_pack_host(admm_ctx *ctx, int32_t *host_send);
 int admm_exchange_unpack_host(admm_ctx *ctx, const int32_t *host_recv);
-/* Grid::Update + UpdateMuArrAfterComm (Grid.cpp:186-193, 163-181). */
+/* Grid::Update + UpdateMuArrAfterComm (Grid.cpp:186-193, 163-181).  Chain
+ * solver: the consensus of a node is a function of the two labels it received,
+ * so Update only makes the newest labels of every set of chains the ones the
+ * crossing chains see from the next admm_compute on (a transposition of both
+ * label arrays, or, on one strip where the sweep can read them in place, a
+ * change of two pointers and no launch). */
 int admm_update(admm_ctx *ctx);
 /* Grid::ComputeLinearObj (Grid.cpp:1665-1680): this strip's share of
  * rho * sum over trees of <theta, mu>; the caller sums over strips as
@@ -156,7 +161,10 @@ int admm_objective(admm_ctx *ctx, double *primal, double *dual);
  * for the stream and copies slots [slot, slot+n) out.  The reference prints
  * its objective every iteration (admm.cpp:94-99); a driver that wants the
  * same trace without a host round trip per iteration queues one slot per
- * iteration and reads them at the end. */
+ * iteration and reads them at the end.  A queued slot is complete after the
+ * second admm_compute that follows (its sums ride along with those launches),
+ * or as soon as admm_objective_read asks for it, whichever comes first (the
+ * two ways add the same binary64 terms, the unary ones in a different order). */
 int admm_objective_enqueue(admm_ctx *ctx, int slot);
 int admm_objective_read(admm_ctx *ctx, int slot, int n, double *linear);
 /* Waits for everything queued on the context's stream. */
