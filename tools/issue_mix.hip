@@ -24,6 +24,8 @@ __global__ __launch_bounds__(64) void mix_kernel(float *out, unsigned long long 
   __shared__ float s_buf[64];
   s_buf[threadIdx.x] = y0;
   const unsigned ldsaddr = (unsigned)(size_t)s_buf;
+  double d0 = y0, d1 = y1, d2 = y2, d3 = y3, dseed = seed, d2in = seed + 1.0;
+  const f2 pone = {1.0f, 1.0f};
   const unsigned long long msk = 0x5555555555555555ull * (unsigned)sseed;
   const unsigned vmsk = (threadIdx.x & 1) ? ~0u : 0u;
   int s0 = sseed, s1 = sseed + 1, s2 = sseed + 2, s3 = sseed + 3, s4 = sseed + 4, s5 = sseed + 5, s6 = sseed + 6, s7 = sseed + 7;
@@ -104,6 +106,85 @@ __global__ __launch_bounds__(64) void mix_kernel(float *out, unsigned long long 
                    "v_cmp_lt_f32_e32 vcc, %1, %4\n\tv_add_f32_e32 %0, %0, %4\n\tv_add_f32_e32 %2, %2, %4\n\tv_cndmask_b32_e32 %3, %3, %4, vcc"
                    : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3) : "v"(seed) : "vcc");
     }
+    if constexpr (KIND == 16) {  // 8 conversions int32 -> binary32
+      asm volatile("v_cvt_f32_i32_e32 %0, %0\n\t"
+                   "v_cvt_f32_i32_e32 %1, %1\n\t"
+                   "v_cvt_f32_i32_e32 %2, %2\n\t"
+                   "v_cvt_f32_i32_e32 %3, %3\n\t"
+                   "v_cvt_f32_i32_e32 %4, %4\n\t"
+                   "v_cvt_f32_i32_e32 %5, %5\n\t"
+                   "v_cvt_f32_i32_e32 %6, %6\n\t"
+                   "v_cvt_f32_i32_e32 %7, %7"
+                   : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7) : "v"(seed), "v"(vmsk));
+    }
+    if constexpr (KIND == 17) {  // 8 x (conversion binary32 -> binary64, binary64 add)
+      asm volatile("v_cvt_f64_f32_e32 %0, %4\n\tv_add_f64 %2, %2, %0\n\tv_cvt_f64_f32_e32 %1, %5\n\tv_add_f64 %3, %3, %1\n\t"
+                   "v_cvt_f64_f32_e32 %0, %6\n\tv_add_f64 %2, %2, %0\n\tv_cvt_f64_f32_e32 %1, %7\n\tv_add_f64 %3, %3, %1"
+                   : "=&v"(d0), "=&v"(d1), "+v"(d2), "+v"(d3) : "v"(y0), "v"(y1), "v"(y2), "v"(y3));
+    }
+    if constexpr (KIND == 18) {  // 8 binary64 adds
+      asm volatile("v_add_f64 %0, %0, %4\n\tv_add_f64 %1, %1, %4\n\tv_add_f64 %2, %2, %4\n\tv_add_f64 %3, %3, %4\n\t"
+                   "v_add_f64 %0, %0, %4\n\tv_add_f64 %1, %1, %4\n\tv_add_f64 %2, %2, %4\n\tv_add_f64 %3, %3, %4"
+                   : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(dseed));
+    }
+    if constexpr (KIND == 19) {  // 8 conversions binary32 -> binary64
+      asm volatile("v_cvt_f64_f32_e32 %0, %4\n\tv_cvt_f64_f32_e32 %1, %5\n\tv_cvt_f64_f32_e32 %2, %6\n\tv_cvt_f64_f32_e32 %3, %7\n\t"
+                   "v_cvt_f64_f32_e32 %0, %5\n\tv_cvt_f64_f32_e32 %1, %6\n\tv_cvt_f64_f32_e32 %2, %7\n\tv_cvt_f64_f32_e32 %3, %4"
+                   : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) : "v"(y0), "v"(y1), "v"(y2), "v"(y3));
+      y4 += (float)d0 + (float)d1 + (float)d2 + (float)d3;
+    }
+    if constexpr (KIND == 20) {  // 8 64-bit moves
+      asm volatile("v_mov_b64 %0, %4\n\tv_mov_b64 %1, %4\n\tv_mov_b64 %2, %4\n\tv_mov_b64 %3, %4\n\t"
+                   "v_mov_b64 %0, %5\n\tv_mov_b64 %1, %5\n\tv_mov_b64 %2, %5\n\tv_mov_b64 %3, %5"
+                   : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) : "v"(dseed), "v"(d2in));
+      y4 += (float)d0 + (float)d1 + (float)d2 + (float)d3;
+    }
+    if constexpr (KIND == 21) {  // 8 24-bit multiply-adds
+      asm volatile("v_mad_i32_i24 %0, %0, %9, %8\n\t"
+                   "v_mad_i32_i24 %1, %1, %9, %8\n\t"
+                   "v_mad_i32_i24 %2, %2, %9, %8\n\t"
+                   "v_mad_i32_i24 %3, %3, %9, %8\n\t"
+                   "v_mad_i32_i24 %4, %4, %9, %8\n\t"
+                   "v_mad_i32_i24 %5, %5, %9, %8\n\t"
+                   "v_mad_i32_i24 %6, %6, %9, %8\n\t"
+                   "v_mad_i32_i24 %7, %7, %9, %8"
+                   : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7) : "v"(seed), "v"(vmsk));
+    }
+    if constexpr (KIND == 22) {  // 8 three-input medians
+      asm volatile("v_med3_f32 %0, %0, %8, %9\n\t"
+                   "v_med3_f32 %1, %1, %8, %9\n\t"
+                   "v_med3_f32 %2, %2, %8, %9\n\t"
+                   "v_med3_f32 %3, %3, %8, %9\n\t"
+                   "v_med3_f32 %4, %4, %8, %9\n\t"
+                   "v_med3_f32 %5, %5, %8, %9\n\t"
+                   "v_med3_f32 %6, %6, %8, %9\n\t"
+                   "v_med3_f32 %7, %7, %8, %9"
+                   : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7) : "v"(seed), "v"(vmsk));
+    }
+    if constexpr (KIND == 23) {  // 8 packed multiplies
+      asm volatile("v_pk_mul_f32 %0, %0, %4\n\tv_pk_mul_f32 %1, %1, %4\n\tv_pk_mul_f32 %2, %2, %4\n\tv_pk_mul_f32 %3, %3, %4\n\t"
+                   "v_pk_mul_f32 %0, %0, %4\n\tv_pk_mul_f32 %1, %1, %4\n\tv_pk_mul_f32 %2, %2, %4\n\tv_pk_mul_f32 %3, %3, %4"
+                   : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pone));
+    }
+    if constexpr (KIND == 24) {  // 8 multiplies
+      asm volatile("v_mul_f32_e32 %0, %0, %8\n\t"
+                   "v_mul_f32_e32 %1, %1, %8\n\t"
+                   "v_mul_f32_e32 %2, %2, %8\n\t"
+                   "v_mul_f32_e32 %3, %3, %8\n\t"
+                   "v_mul_f32_e32 %4, %4, %8\n\t"
+                   "v_mul_f32_e32 %5, %5, %8\n\t"
+                   "v_mul_f32_e32 %6, %6, %8\n\t"
+                   "v_mul_f32_e32 %7, %7, %8"
+                   : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7) : "v"(seed), "v"(vmsk));
+    }
+    if constexpr (KIND == 25) {  // 8 cross-lane minima two instructions apart (DPP quad swap), adds between
+      asm volatile("v_min_f32_dpp %0, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_add_f32_e32 %5, %5, %8\n\tv_add_f32_e32 %6, %6, %8\n\t"
+                   "v_min_f32_dpp %1, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\tv_add_f32_e32 %7, %7, %8\n\tv_add_f32_e32 %5, %5, %8\n\t"
+                   "v_min_f32_dpp %2, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\tv_add_f32_e32 %6, %6, %8\n\tv_add_f32_e32 %7, %7, %8\n\t"
+                   "v_min_f32_dpp %3, %2, %2 row_mirror row_mask:0xf bank_mask:0xf"
+                   : "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7) : "v"(seed));
+      y4 += y3;
+    }
     if constexpr (KIND == 3) {  // interleaved: v s v s ...
       asm volatile("v_add_f32_e32 %0, %0, %16\n\ts_add_i32 %8, %8, %17\n\tv_add_f32_e32 %1, %1, %16\n\ts_add_i32 %9, %9, %17\n\t"
                    "v_add_f32_e32 %2, %2, %16\n\ts_add_i32 %10, %10, %17\n\tv_add_f32_e32 %3, %3, %16\n\ts_add_i32 %11, %11, %17\n\t"
@@ -115,6 +196,7 @@ __global__ __launch_bounds__(64) void mix_kernel(float *out, unsigned long long 
     }
   }
   const unsigned long long t1 = __builtin_readcyclecounter();
+  y0 += (float)(d0 + d1 + d2 + d3);
   y0 += p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
   out[blockIdx.x * 64 + threadIdx.x] = y0 + y1 + y2 + y3 + y4 + y5 + y6 + y7 + (float)(s0 + s1 + s2 + s3 + s4 + s5 + s6 + s7);
   if (threadIdx.x == 0) {
@@ -166,6 +248,16 @@ int main() {
     run<14>("8 compares into scalar pairs", W);
     run<15>("2 x (compare, 2 adds, select)", W);
     run<7>("8 lane reads", W);
+    run<24>("8 multiplies", W);
+    run<23>("8 packed multiplies", W);
+    run<22>("8 three-input medians", W);
+    run<21>("8 24-bit multiply-adds", W);
+    run<16>("8 conversions int32 -> binary32", W);
+    run<19>("8 conversions binary32 -> binary64", W);
+    run<18>("8 binary64 adds", W);
+    run<17>("4 x (convert to binary64, add)", W);
+    run<20>("8 64-bit moves", W);
+    run<25>("4 DPP minima + 6 adds", W);
     run<6>("8 LDS reads of 16 B + wait", W);
     run<9>("8 LDS reads of 4 B + wait", W);
   }
