@@ -1167,26 +1167,29 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
             // two wait states between a vector write of a scalar register and its use.  eqf:
             // the lanes whose far term attains C; eqc: the lanes whose minimum is the far one.
             int off;
-            unsigned long long eqf, eqc, ma, mb, mc;
-            asm("v_cmp_eq_f32_e64 %[ma], %[cp2], %[best]\n\t"
-                "v_cmp_eq_f32_e64 %[mb], %[cp1], %[best]\n\t"
-                "v_cmp_eq_f32_e64 %[mc], %[cp0], %[best]\n\t"
-                "v_cndmask_b32_e64 %[off], 64, 3, %[ma]\n\t"
-                "v_cmp_eq_f32_e64 %[ma], %[c0], %[best]\n\t"
-                "v_cndmask_b32_e64 %[off], %[off], 2, %[mb]\n\t"
-                "v_cmp_eq_f32_e64 %[mb], %[cm0], %[best]\n\t"
-                "v_cndmask_b32_e64 %[off], %[off], 1, %[mc]\n\t"
-                "v_cmp_eq_f32_e64 %[mc], %[cm1], %[best]\n\t"
-                "v_cndmask_b32_e64 %[off], %[off], 0, %[ma]\n\t"
-                "v_cmp_eq_f32_e64 %[ma], %[cm2], %[best]\n\t"
-                "v_cndmask_b32_e64 %[off], %[off], -1, %[mb]\n\t"
+            unsigned long long eqf, eqc, ma, mb;
+            // (Every third compare goes into vcc: a compare into any other scalar pair costs a lone
+            // wavefront 9.9 clock ticks, one into vcc 4.8.)
+            asm("v_cmp_eq_f32_e32 vcc, %[cp2], %[best]\n\t"
+                "v_cmp_eq_f32_e64 %[ma], %[cp1], %[best]\n\t"
+                "v_cmp_eq_f32_e64 %[mb], %[cp0], %[best]\n\t"
+                "v_cndmask_b32_e32 %[off], 64, %[three], vcc\n\t"
+                "v_cmp_eq_f32_e32 vcc, %[c0], %[best]\n\t"
+                "v_cndmask_b32_e64 %[off], %[off], 2, %[ma]\n\t"
+                "v_cndmask_b32_e64 %[off], %[off], 1, %[mb]\n\t"
+                "v_cmp_eq_f32_e64 %[ma], %[cm0], %[best]\n\t"
+                "v_cndmask_b32_e64 %[off], %[off], 0, vcc\n\t"
+                "v_cmp_eq_f32_e32 vcc, %[cm1], %[best]\n\t"
+                "v_cmp_eq_f32_e64 %[mb], %[cm2], %[best]\n\t"
+                "v_cndmask_b32_e64 %[off], %[off], -1, %[ma]\n\t"
                 "v_cmp_eq_f32_e64 %[eqf], %[cf], %[C]\n\t"
+                "v_cndmask_b32_e64 %[off], %[off], -2, vcc\n\t"
                 "v_cmp_eq_f32_e64 %[eqc], %[best], %[C]\n\t"
-                "v_cndmask_b32_e64 %[off], %[off], -2, %[mc]\n\t"
-                "v_cndmask_b32_e64 %[off], %[off], -3, %[ma]"
-                : [off] "=&v"(off), [ma] "=&s"(ma), [mb] "=&s"(mb), [mc] "=&s"(mc), [eqf] "=&s"(eqf), [eqc] "=&s"(eqc)
+                "v_cndmask_b32_e64 %[off], %[off], -3, %[mb]"
+                : [off] "=&v"(off), [ma] "=&s"(ma), [mb] "=&s"(mb), [eqf] "=&s"(eqf), [eqc] "=&s"(eqc)
                 : [cm0] "v"(cm0), [cm1] "v"(cm1), [cm2] "v"(cm2), [c0] "v"(c0), [cp0] "v"(cp0), [cp1] "v"(cp1), [cp2] "v"(cp2), [cf] "v"(cf),
-                  [C] "v"(C), [best] "v"(best));
+                  [C] "v"(C), [best] "v"(best), [three] "v"(3)
+                : "vcc");
             // i_far: the lowest lane of this lane's chain whose far term attains C
             const int ifar = __builtin_ctz((unsigned)(eqf >> (cs * LPC)) | (1u << (KP - 1)));
             const int nearest = b + off;  // >= k when no near source attains the minimum (then it equals C)
