@@ -323,6 +323,13 @@ bool is_chain(const admm_ctx *c) { return c->d.solver == ADMM_SOLVER_CHAIN_MINSU
 
 // ------------------------------------------------------------------ chain launches
 
+// ADMM_SWEEP_LDS_PAD=<bytes> (tuning knob): dynamic LDS a sweep launch asks for on top of what
+// it uses, which lowers the number of workgroups a compute unit holds.
+inline unsigned sweep_pad_lds() {
+  const char *e = getenv("ADMM_SWEEP_LDS_PAD");
+  return e ? (unsigned)std::max(0, atoi(e)) : 0u;
+}
+
 struct SweepShape {
   int KP, NS;
 };
@@ -361,7 +368,7 @@ constexpr int sweep_minw(int KP, int NS) { return (KP / NS >= 32 || NS > 1) ? 2 
 
 template <int KP, int NS, bool DUAL>
 void launch_sweep_t(const ChainArgs &a, int blocks, hipStream_t s) {
-  hipLaunchKernelGGL((chain_sweep_kernel<KP, NS, sweep_gpb(KP, NS), sweep_minw(KP, NS), DUAL>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+  hipLaunchKernelGGL((chain_sweep_kernel<KP, NS, sweep_gpb(KP, NS), sweep_minw(KP, NS), DUAL>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
 }
 
 // Two wavefronts per half chain (the kernels built with SPLIT), for launches with at most one
@@ -379,22 +386,22 @@ bool twowave_chosen(int KP, int waves, bool trunc = false) {
 }
 template <int KP>
 void launch_sweep_potts_split_t(const ChainArgs &a, int blocks, hipStream_t s, bool lam16, bool lam8) {
-  if (lam8) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, false, true, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
-  else if (lam16) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, false, false, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
-  else hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, false, false, false, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+  if (lam8) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, false, true, true>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
+  else if (lam16) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, false, false, true>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
+  else hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, false, false, false, true>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
 }
 
 template <int KP, bool PCOMP = false>
 void launch_sweep_potts_t(const ChainArgs &a, int blocks, hipStream_t s) {
   // a step needs few registers: four wavefronts per SIMD, operands fetched 8 steps ahead
   // (16 ahead changes nothing: the kernel moves its bytes at the rate a streaming kernel does)
-  hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, false, PCOMP>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+  hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, false, PCOMP>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
 }
 template <int KP, bool PCOMP = false>
 void launch_sweep_potts16_t(const ChainArgs &a, int blocks, hipStream_t s, bool lam8) {
   // (operands 16 steps ahead instead of 8: 1 to 2 % slower; 32: spills)
-  if (lam8) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, PCOMP, true>), dim3(blocks), dim3(kChainBlock), 0, s, a);
-  else hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, PCOMP>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+  if (lam8) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, PCOMP, true>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
+  else hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, PCOMP>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
 }
 
 // Path compression in the Potts kernel (the forward pass tracks, per block of eight
@@ -518,15 +525,15 @@ int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
   if (trunc && twowave_chosen(sh.KP, w, true)) {
     a.mix_blocks = 0;
     a.red_block = w / 2;
-    if (c->lam16 && c->lam8) hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, true, false, true, true, 3>), dim3(w_split), dim3(kChainBlock), 0, s, a);
-    else if (c->lam16) hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, true, false, false, true, 3>), dim3(w_split), dim3(kChainBlock), 0, s, a);
-    else hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, false, false, false, true, 3>), dim3(w_split), dim3(kChainBlock), 0, s, a);
+    if (c->lam16 && c->lam8) hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, true, false, true, true, 3>), dim3(w_split), dim3(kChainBlock), sweep_pad_lds(), s, a);
+    else if (c->lam16) hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, true, false, false, true, 3>), dim3(w_split), dim3(kChainBlock), sweep_pad_lds(), s, a);
+    else hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, false, false, false, true, 3>), dim3(w_split), dim3(kChainBlock), sweep_pad_lds(), s, a);
     goto launched;
   }
   if (trunc) {
-    if (c->lam16 && c->lam8) hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, true, false, true, false, 3>), dim3(blocks), dim3(kChainBlock), 0, s, a);
-    else if (c->lam16) hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, true, false, false, false, 3>), dim3(blocks), dim3(kChainBlock), 0, s, a);
-    else hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, false, false, false, false, 3>), dim3(blocks), dim3(kChainBlock), 0, s, a);
+    if (c->lam16 && c->lam8) hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, true, false, true, false, 3>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
+    else if (c->lam16) hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, true, false, false, false, 3>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
+    else hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, false, false, false, false, 3>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
     goto launched;
   }
 #define SWEEP_CASE(kp, ns) \
