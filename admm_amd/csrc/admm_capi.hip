@@ -536,6 +536,18 @@ int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
     else hipLaunchKernelGGL((chain_sweep_kernel<16, 1, 8, 4, false, false, false, false, false, false, 3>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
     goto launched;
   }
+  if (!DUAL && c->lam16) {
+    // the general step on integer counts (one lane per label; admm_init chose the counts only then)
+#define SWEEP_COUNTS(kp) \
+  if (sh.KP == kp && sh.NS == 1) { \
+    if (c->lam8) hipLaunchKernelGGL((chain_sweep_kernel<kp, 1, sweep_gpb(kp, 1), sweep_minw(kp, 1), false, false, true, false, true>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a); \
+    else hipLaunchKernelGGL((chain_sweep_kernel<kp, 1, sweep_gpb(kp, 1), sweep_minw(kp, 1), false, false, true, false, false>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a); \
+    goto launched; \
+  }
+    SWEEP_COUNTS(16) SWEEP_COUNTS(32)
+#undef SWEEP_COUNTS
+    return fail(c, ADMM_E_STATE, "no sweep kernel on integer counts for KP=%d NS=%d", sh.KP, sh.NS);
+  }
 #define SWEEP_CASE(kp, ns) \
   if (sh.KP == kp && sh.NS == ns) { launch_sweep_t<kp, ns, DUAL>(a, blocks, s); goto launched; }
   SWEEP_CASE(2, 1) SWEEP_CASE(2, 2)
@@ -1643,7 +1655,17 @@ int admm_init(admm_ctx *c) {
       int ex = 0;
       const bool pow2 = hpen > 0.0f && std::frexp(hpen, &ex) == 0.5f && ex > -100 && ex < 100;
       const char *e16 = getenv("ADMM_LAM16"), *elim = getenv("ADMM_LAM16_LIMIT");
-      c->lam16 = ((potts && c->KP >= 8 && potts_enabled()) || c->trunc3) && pow2 && !(e16 && atoi(e16) == 0);
+      // (the general kernel: with one lane per label and 16 or 32 label lanes, where the bytes count -
+      // 2048 x 2048 with a dense table, k = 16: 0.339 -> 0.297 ms per iteration, k = 32: 0.841 -> 0.830;
+      // 64 labels are bound by the vector ALU and lose 1 % to the conversions; ADMM_LAM16_GENERAL=0
+      // keeps binary32)
+      bool general_counts = false;
+      {
+        const SweepShape shg = pick_shape(c->KP, (long long)d.batch * c->st.nrows + (long long)d.batch * c->st.ncols);
+        const char *eg = getenv("ADMM_LAM16_GENERAL");
+        general_counts = shg.NS == 1 && (c->KP == 16 || c->KP == 32) && !(eg && atoi(eg) == 0);
+      }
+      c->lam16 = ((potts && c->KP >= 8 && potts_enabled()) || c->trunc3 || general_counts) && pow2 && !(e16 && atoi(e16) == 0);
       c->lam16_sweeps = 0;
       c->lam16_limit = elim ? std::max(0, std::min(32000, atoi(elim))) : 32000;
       // int8 counts: ADMM_LAM8=0 never; ADMM_LAM8_THR / ADMM_LAM8_EVERY move the scan's threshold and
@@ -2660,7 +2682,8 @@ int admm_sweep_kernel_name(admm_ctx *c, char *buf, int len) {
              (c->lam16 && c->lam8) ? "true" : "false", twowave_chosen(16, waves, true) ? "true" : "false");
   }
   else
-    snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, %d, %d, %d, false, false, false, false, false, false, 0>", sh.KP, sh.NS, sweep_gpb(sh.KP, sh.NS), sweep_minw(sh.KP, sh.NS));
+    snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, %d, %d, %d, false, false, %s, false, %s, false, 0>", sh.KP, sh.NS, sweep_gpb(sh.KP, sh.NS), sweep_minw(sh.KP, sh.NS),
+             c->lam16 ? "true" : "false", (c->lam16 && c->lam8) ? "true" : "false");
   return ADMM_OK;
 }
 

@@ -887,8 +887,8 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
       xown = s_x[wib][cs][tt0 + s];
       xoth = s_xo[wib][cs][tt0 + s];
     }
-    // Potts or truncated step on integer counts: the shell of two steps at a time (PAIRED)
-    constexpr bool PAIRED = (POTTS || TRUNC > 0) && LAM16 && GPB % 2 == 0;
+    // integer counts: the shell of two steps at a time (PAIRED), whatever the step
+    constexpr bool PAIRED = LAM16 && GPB % 2 == 0;
     int xown1 = -1, xoth1 = -1;  // labels of the step after the current one
     float th_pair = INF;         // adjusted unary of the odd step, worked out with the even one
     if constexpr (PAIRED && SHELL && !XPRE) {

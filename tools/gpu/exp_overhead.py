@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import admm_amd as A
 
 W = {"2048": (2048, 2048, 32, 1, "potts"), "512": (512, 512, 16, 1, "trunc_linear"), "64": (64, 64, 4, 1, "potts"),
-     "batch": (256, 256, 8, 256, "potts"), "dense": (1024, 1024, 64, 1, "dense")}
+     "batch": (256, 256, 8, 256, "potts"), "dense": (1024, 1024, 64, 1, "dense"), "dense32": (2048, 2048, 32, 1, "dense"),
+     "dense16": (2048, 2048, 16, 1, "dense"), "trunc32": (2048, 2048, 32, 1, "trunc_linear")}
 names = sys.argv[1].split(",")
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 for name in names:
