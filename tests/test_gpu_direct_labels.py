@@ -166,3 +166,24 @@ def test_full_size_headline_both_forms(monkeypatch):
     for a, b in zip(res[0][:3], res[1][:3]):
         assert np.array_equal(a, b)
     assert res[0][3] == res[1][3]
+
+
+@pytest.mark.parametrize("knob,value", [("ADMM_SWEEP_XCD", "1"), ("ADMM_SWEEP_XCD", "0"), ("ADMM_SWEEP_LDS_PAD", "40000")])
+@pytest.mark.parametrize("R,C,k,pw,B", [(40, 40, 8, "potts", 20), (300, 70, 32, "potts", 1), (64, 200, 16, "trunc_linear", 2)])
+def test_placement_knobs_change_no_result(knob, value, R, C, k, pw, B, monkeypatch):
+    """Which die a workgroup's chains run on and how many workgroups a compute unit holds are
+    tuning choices: the labels and the objective must not depend on them."""
+    un, W = _problem(R, C, k, pw, B, 77)
+    out = []
+    for setting in (None, value):
+        if setting is None:
+            monkeypatch.delenv(knob, raising=False)
+        else:
+            monkeypatch.setenv(knob, setting)
+        g = _grid(R, C, k, un, W, B)
+        for _ in range(5):
+            g.Compute(); g.Communicate(); g.Update()
+        out.append(_snapshot(g) + [np.array([g.ComputeLinearObj()])])
+        g.close()
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
