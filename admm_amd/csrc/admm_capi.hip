@@ -84,6 +84,8 @@ struct admm_ctx {
   float *d_mu_edge = nullptr, *d_pot_edge = nullptr, *d_m_vert = nullptr;
   double *d_partial = nullptr;
   int n_partial = 0;
+  double *d_edge_obj = nullptr;  // edge solver: one objective term per workgroup of the last solve
+  int edge_obj_n = 0;            // terms the last solve wrote; 0 = none since admm_init
   double *d_obj_slots = nullptr;  // [n_obj_slots][2] (primal, linear) queued objective values
   int n_obj_slots = 0;
   // edge solver on several ranks (EDGE partition, Grid.cpp:445-454): V and E
@@ -1070,11 +1072,14 @@ void build_incidence(admm_ctx *c) {
   for (int i = 0; i < 2 * c->E; i++) c->h_inc[fillp[c->h_edges[i]]++] = i;
 }
 
+int edge_blocks(int E, int KP) {
+  const int gpb = (kEdgeBlock / 64) * (64 / KP);
+  return (E + gpb - 1) / gpb;
+}
+
 template <int KP>
 void launch_edge_t(const EdgeArgs &a, hipStream_t s) {
-  constexpr int GPB = (kEdgeBlock / 64) * (64 / KP);
-  const int blocks = (a.E + GPB - 1) / GPB;
-  hipLaunchKernelGGL((edge_solve_kernel<KP>), dim3(blocks), dim3(kEdgeBlock), 0, s, a);
+  hipLaunchKernelGGL((edge_solve_kernel<KP>), dim3(edge_blocks(a.E, KP)), dim3(kEdgeBlock), 0, s, a);
 }
 
 int edge_compute(admm_ctx *c) {
@@ -1085,6 +1090,7 @@ int edge_compute(admm_ctx *c) {
   a.edgeList = c->d_edges;
   a.mu_node = c->d_mu_node; a.pot_node = c->d_pot_node; a.lam_node = c->d_lam_node;
   a.mu_edge = c->d_mu_edge; a.pot_edge = c->d_pot_edge; a.m_vert = c->d_m_vert;
+  a.obj_part = c->d_edge_obj;
   switch (c->KP) {
     case 2: launch_edge_t<2>(a, c->stream); break;
     case 4: launch_edge_t<4>(a, c->stream); break;
@@ -1095,6 +1101,7 @@ int edge_compute(admm_ctx *c) {
     default: return fail(c, ADMM_E_ARG, "edge solver supports k <= 64 (k=%d)", c->d.k);
   }
   HIP_TRY(c, hipGetLastError());
+  c->edge_obj_n = c->d_edge_obj ? edge_blocks(c->E, c->KP) : 0;
   return ADMM_OK;
 }
 
@@ -1254,6 +1261,13 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
     }
     c->n_partial = 1024;
     if ((rc = dev_alloc(c, &c->d_partial, (size_t)c->n_partial))) return bail(rc);
+    // ADMM_EDGE_FUSED_OBJ=0 (test knob): the solve sums nothing and the objective is always the
+    // separate pass over the marginals
+    const char *fo = getenv("ADMM_EDGE_FUSED_OBJ");
+    c->edge_obj_n = 0;
+    if (c->KP <= 64 && !(fo && atoi(fo) == 0) &&
+        (rc = dev_alloc(c, &c->d_edge_obj, (size_t)edge_blocks(c->E, c->KP))))
+      return bail(rc);
     hipError_t e1 = h2d_sync(c, c->d_edges, c->h_edges.data(), sizeof(int) * 2 * E);
     hipError_t e2 = h2d_sync(c, c->d_inc_off, c->h_inc_off.data(), sizeof(int) * (V + 1));
     hipError_t e3 = h2d_sync(c, c->d_inc, c->h_inc.data(), sizeof(int) * 2 * E);
@@ -2342,6 +2356,16 @@ int admm_linear_objective(admm_ctx *c, double *obj) {
     HIP_TRY(c, hipMemcpyAsync(h, c->d_obj_slots, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     *obj = (h[0] + h[1]) * c->d.rho;
+    return ADMM_OK;
+  }
+  if (c->edge_obj_n > 0) {  // the last solve summed its own marginals, workgroup by workgroup
+    hipLaunchKernelGGL(edge_objective_sum_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_partial, c->d_edge_obj,
+                       c->edge_obj_n);
+    HIP_TRY(c, hipGetLastError());
+    double h = 0.0;
+    HIP_TRY(c, hipMemcpyAsync(&h, c->d_partial, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *obj = h * c->d.rho;
     return ADMM_OK;
   }
   const long long nn = (long long)c->E * 2 * c->d.k, ne = (long long)c->E * c->d.k * c->d.k;

@@ -21,6 +21,7 @@ struct EdgeArgs {
   float *mu_edge;         // [E][k*k] x_mu_edge
   const float *pot_edge;  // [E][k*k] x_potential_edge
   const float *m_vert;    // [V][k]   consensus (what edge_mu_node holds)
+  double *obj_part;       // [workgroups] linear objective of the new marginals, or null
 };
 
 __device__ __forceinline__ void edge_lds_fence() {
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
 
   // node vectors: UpdateLambda, AdjustPotentials, UpdateMu, node derivatives
   // and node potentials (Tree.cpp:64-73, 84-86, 48-51, 120-122, 141-143, 157-160)
+  float pot_h[2];
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     const int v = p.edgeList[2 * e + h];
@@ -71,6 +73,7 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
       lam = p.lam_node[e * 2 * k + h * k + i];
       pot = p.pot_node[e * 2 * k + h * k + i];
     }
+    pot_h[h] = pot;
     lam = lam + pen * (mu - m);
     if (wr) p.lam_node[e * 2 * k + h * k + i] = lam;
     const float xnode = rho * (pot + lam) - pen * (m - mu);
@@ -160,8 +163,54 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
     ep[i * LD + b] = (acc != 0.0f) ? (mu1 * ex / acc) : 0.0f;
   }
   edge_lds_fence();
-  if (wr)
-    for (int a = 0; a < k; a++) p.mu_edge[e * k2 + a * k + i] = ep[a * LD + i];
+  if (p.obj_part == nullptr) {
+    if (wr)
+      for (int a = 0; a < k; a++) p.mu_edge[e * k2 + a * k + i] = ep[a * LD + i];
+    return;
+  }
+  // ... and the linear objective of the marginals just written (Grid.cpp:1665-1680: binary32
+  // products accumulated in binary64), one partial sum per workgroup, so that asking for the
+  // objective after a solve does not read the marginals and the potentials again
+  __shared__ double s_obj[kEdgeBlock / 64];
+  double oacc = 0.0;
+  if (wr) {
+    const float n1 = pot_h[0] * mu1, n2 = pot_h[1] * mu2;
+    oacc = (double)n1 + (double)n2;
+    // (the potentials are read a second time: a column of them kept in registers needs both
+    // loops unrolled by the lane count, which ran twenty times slower at 32 labels)
+    for (int a = 0; a < k; a++) {
+      const float m = ep[a * LD + i];
+      p.mu_edge[e * k2 + a * k + i] = m;
+      const float pr = p.pot_edge[e * k2 + a * k + i] * m;
+      oacc += (double)pr;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) oacc += __shfl_xor(oacc, d);
+  if ((threadIdx.x & 63) == 0) s_obj[threadIdx.x >> 6] = oacc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = s_obj[0];
+    for (int w = 1; w < kEdgeBlock / 64; w++) t += s_obj[w];
+    p.obj_part[blockIdx.x] = t;
+  }
+}
+
+// Sum of the solve's per-workgroup objective terms: one workgroup, one value.
+__global__ __launch_bounds__(1024) void edge_objective_sum_kernel(double *__restrict__ dst,
+                                                                   const double *__restrict__ part, int n) {
+  __shared__ double s_red[16];
+  double acc = 0.0;
+  for (int q = threadIdx.x; q < n; q += 1024) acc += part[q];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = s_red[0];
+    for (int w = 1; w < 16; w++) t += s_red[w];
+    dst[0] = t;
+  }
 }
 
 // Consensus (Grid.cpp:144-148 + Tree.cpp:244,253 + Grid.cpp:163-181): the

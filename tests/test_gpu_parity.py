@@ -353,6 +353,30 @@ def test_edge_clamps_non_positive_marginals():
     g.close()
 
 
+@pytest.mark.parametrize("R,C,k", [(3, 3, 2), (9, 7, 3), (17, 5, 8), (6, 11, 16), (13, 9, 32), (5, 7, 64), (40, 33, 5)])
+def test_edge_objective_summed_by_the_solve_equals_the_separate_pass(R, C, k, monkeypatch):
+    """The solve sums the linear objective of the marginals it writes (one term per workgroup);
+    ADMM_EDGE_FUSED_OBJ=0 keeps the separate pass over marginals and potentials.  The same
+    binary32 products in another binary64 order; before the first solve both are the separate pass."""
+    from oracle import oracle as O
+    un, _ = O.synth_problem(R, C, k, 5, "potts")
+    E = O.grid_edges(R, C).size // 2
+    ep, _ = O.lcg_fill(99, E * k * k)
+    monkeypatch.setenv("ADMM_EDGE_FUSED_OBJ", "0")
+    gs = _edge_grid(R, C, k, un, ep, per_edge=True)
+    monkeypatch.delenv("ADMM_EDGE_FUSED_OBJ")
+    gf = _edge_grid(R, C, k, un, ep, per_edge=True)
+    assert gs.ComputeLinearObj() == gf.ComputeLinearObj()
+    for it in range(6):
+        _step(gs); _step(gf)
+        a, b = gs.ComputeLinearObj(), gf.ComputeLinearObj()
+        assert abs(a - b) <= 1e-12 * abs(a), (it, a, b)
+        assert b == gf.ComputeLinearObj()        # asked twice: the same sum
+    for which in (0, 3, 4):
+        assert np.array_equal(gs.State(which), gf.State(which))
+    gs.close(); gf.close()
+
+
 # ---------------------------------------------------------------- call-order errors
 
 def test_call_order_errors():
