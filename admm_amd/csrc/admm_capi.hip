@@ -1128,6 +1128,24 @@ int admm_device_count(void) {
 
 const char *admm_version(void) { return "admm_hip 0.1 (gfx950)"; }
 
+int admm_edge_log_values(int device, const double *x, double *y, int64_t n) {
+  if (!x || !y || n < 0) return ADMM_E_ARG;
+  if (n == 0) return ADMM_OK;
+  if (hipSetDevice(device) != hipSuccess) return ADMM_E_HIP;
+  double *dx = nullptr, *dy = nullptr;
+  int rc = ADMM_E_HIP;
+  if (hipMalloc((void **)&dx, sizeof(double) * (size_t)n) == hipSuccess &&
+      hipMalloc((void **)&dy, sizeof(double) * (size_t)n) == hipSuccess &&
+      hipMemcpy(dx, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess) {
+    hipLaunchKernelGGL(edge_log_values_kernel, dim3(grid_for(n, kEdgeBlock)), dim3(kEdgeBlock), 0, 0, dy, dx, (long long)n);
+    if (hipGetLastError() == hipSuccess && hipMemcpy(y, dy, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess)
+      rc = ADMM_OK;
+  }
+  (void)hipFree(dx);
+  (void)hipFree(dy);
+  return rc;
+}
+
 const char *admm_last_error(const admm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 void admm_partition(int n, int nranks, int rank, int *start, int *count) {

@@ -2,14 +2,20 @@
 // subproblem, one tree per edge (Tree.h:20-51).  A group of KP lanes owns one
 // edge; lane i holds entry i of the node vectors and walks row / column i of
 // the k x k table, so every running sum is accumulated in the same order as
-// the reference's scalar loops.  log / exp are evaluated in binary64 and
-// rounded to binary32 exactly where the reference stores into a float.
+// the reference's scalar loops.  log / exp are evaluated in binary64 (exp: the
+// device library's; log: edge_log.h, a quarter of the device library's
+// instructions) and rounded to binary32 exactly where the reference stores
+// into a float.
 #pragma once
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "edge_log.h"
+
 namespace admm {
+
+__device__ const double d_log_table[kLogPieces][4] = {ADMM_LOG_TABLE};
 
 struct EdgeArgs {
   int E, V, k;
@@ -43,6 +49,10 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
   __shared__ float s_buf[GPB][KP];
   __shared__ float s_m12[GPB][KP];
   __shared__ float s_m21[GPB][KP];
+  __shared__ __attribute__((aligned(16))) double s_log[kLogPieces][4];
+  static_assert(kLogPieces * 2 == kEdgeBlock, "one 16-byte half row of the table per thread");
+  reinterpret_cast<double2 *>(&s_log[0][0])[threadIdx.x] = reinterpret_cast<const double2 *>(&d_log_table[0][0])[threadIdx.x];
+  __syncthreads();
 
   const int grp = threadIdx.x / KP;
   const int i = threadIdx.x % KP;
@@ -54,6 +64,12 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
   const bool wr = evalid && iv;
   const float EPS = 0.00000000000000001;  // Tree.h:15
   const float pen = p.penalty, pp = p.penaltyPrime, rho = p.rho;
+  // x / penaltyPrime (Tree.cpp:160, 172) for a power of two (1 by default) is x * (1 / penaltyPrime):
+  // the same real number, so the same rounding, without the division's dozen instructions
+  const float inv_pp = 1.0f / pp;
+  const bool pp_pow2 = (__float_as_uint(pp) & 0x807fffffu) == 0 && (__float_as_uint(pp) >> 23) != 0 &&
+                       (__float_as_uint(pp) >> 23) != 255 && (__float_as_uint(inv_pp) & 0x7f800000u) != 0 &&
+                       inv_pp * pp == 1.0f;
 
   float *ep = s_ep[grp];
   float *np = s_np[grp];
@@ -78,29 +94,41 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
     if (wr) p.lam_node[e * 2 * k + h * k + i] = lam;
     const float xnode = rho * (pot + lam) - pen * (m - mu);
     const float muc = ((double)mu <= 0.0) ? EPS : mu;
-    const float lv = (float)log((double)muc);
+    const float lv = (float)edge_log((double)muc, s_log);
     const float nd = (float)(-1.0 - (double)lv);
     float val = xnode + pp * nd;
-    val = val / pp;
+    val = pp_pow2 ? val * inv_pp : val / pp;
     np[h * KP + i] = 0.0f - val;
     lmu[h * KP + i] = lv;
   }
   edge_lds_fence();
 
-  // edge derivatives and potentials (Tree.cpp:123-133, 144-150, 98-99, 169-172)
-  for (int a = 0; a < k; a++) {
-    float mue = 1.0f, pe = 0.0f;
-    if (iv) {
-      mue = p.mu_edge[e * k2 + a * k + i];
-      pe = p.pot_edge[e * k2 + a * k + i];
+  // edge derivatives and potentials (Tree.cpp:123-133, 144-150, 98-99, 169-172), kLoadAhead rows
+  // of the table at a time: their loads leave together, so a wavefront waits for memory once per
+  // batch and not once per row
+  constexpr int kLoadAhead = 8;
+  for (int a0 = 0; a0 < k; a0 += kLoadAhead) {
+    float mue_b[kLoadAhead], pe_b[kLoadAhead];
+#pragma unroll
+    for (int u = 0; u < kLoadAhead; u++) {
+      const bool ok = iv && a0 + u < k;
+      mue_b[u] = ok ? p.mu_edge[e * k2 + (a0 + u) * k + i] : 1.0f;
+      pe_b[u] = ok ? p.pot_edge[e * k2 + (a0 + u) * k + i] : 0.0f;
     }
-    const float muec = ((double)mue <= 0.0) ? EPS : mue;
-    float ed = (float)(((double)lmu[a] - log((double)muec)) + 1.0);
-    ed = ed + lmu[KP + i];
-    const float xe = rho * pe;
-    float val = xe + pp * ed;
-    val = val / pp;
-    ep[a * LD + i] = 0.0f - val;
+#pragma unroll
+    for (int u = 0; u < kLoadAhead; u++) {
+      const int a = a0 + u;
+      if (a < k) {
+        const float mue = mue_b[u], pe = pe_b[u];
+        const float muec = ((double)mue <= 0.0) ? EPS : mue;
+        float ed = (float)(((double)lmu[a] - edge_log((double)muec, s_log)) + 1.0);
+        ed = ed + lmu[KP + i];
+        const float xe = rho * pe;
+        float val = xe + pp * ed;
+        val = pp_pow2 ? val * inv_pp : val / pp;
+        ep[a * LD + i] = 0.0f - val;
+      }
+    }
   }
   edge_lds_fence();
 
@@ -178,11 +206,20 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
     oacc = (double)n1 + (double)n2;
     // (the potentials are read a second time: a column of them kept in registers needs both
     // loops unrolled by the lane count, which ran twenty times slower at 32 labels)
-    for (int a = 0; a < k; a++) {
-      const float m = ep[a * LD + i];
-      p.mu_edge[e * k2 + a * k + i] = m;
-      const float pr = p.pot_edge[e * k2 + a * k + i] * m;
-      oacc += (double)pr;
+    for (int a0 = 0; a0 < k; a0 += kLoadAhead) {
+      float pe_b[kLoadAhead];
+#pragma unroll
+      for (int u = 0; u < kLoadAhead; u++) pe_b[u] = a0 + u < k ? p.pot_edge[e * k2 + (a0 + u) * k + i] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < kLoadAhead; u++) {
+        const int a = a0 + u;
+        if (a < k) {
+          const float m = ep[a * LD + i];
+          p.mu_edge[e * k2 + a * k + i] = m;
+          const float pr = pe_b[u] * m;
+          oacc += (double)pr;
+        }
+      }
     }
   }
 #pragma unroll
@@ -211,6 +248,16 @@ __global__ __launch_bounds__(1024) void edge_objective_sum_kernel(double *__rest
     for (int w = 1; w < 16; w++) t += s_red[w];
     dst[0] = t;
   }
+}
+
+// The solve's logarithm on a list of values (accuracy tests).
+__global__ __launch_bounds__(kEdgeBlock) void edge_log_values_kernel(double *__restrict__ y, const double *__restrict__ x,
+                                                                     long long n) {
+  __shared__ __attribute__((aligned(16))) double s_log[kLogPieces][4];
+  reinterpret_cast<double2 *>(&s_log[0][0])[threadIdx.x] = reinterpret_cast<const double2 *>(&d_log_table[0][0])[threadIdx.x];
+  __syncthreads();
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x)
+    y[idx] = edge_log(x[idx], s_log);
 }
 
 // Consensus (Grid.cpp:144-148 + Tree.cpp:244,253 + Grid.cpp:163-181): the

@@ -265,6 +265,11 @@ int admm_sweep_kernel_info(admm_ctx *ctx, int *label_lanes, int *lanes_per_label
  * timed.  buf receives at most len bytes, NUL-terminated. */
 int admm_sweep_kernel_name(admm_ctx *ctx, char *buf, int len);
 
+/* The binary64 logarithm the edge solver takes of every marginal
+ * (Tree.cpp:120-133), applied on the device to n host values: y[i] = log x[i].
+ * For accuracy tests of that function; no counterpart in the reference. */
+int admm_edge_log_values(int device, const double *x, double *y, int64_t n);
+
 /* Number of HIP devices visible to this process (0 when there is none). */
 int admm_device_count(void);
 
