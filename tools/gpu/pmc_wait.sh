@@ -12,7 +12,7 @@ for f in glob.glob("gpurun_out/$tag/**/*counter_collection.csv", recursive=True)
     for r in csv.DictReader(open(f)):
         per[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in per.items():
-    if "sweep" in k:
+    if "sweep" in k or "edge_solve" in k:
         print(k[:100])
         for c, vals in sorted(v.items()):
             print("   %-24s %.4g" % (c, sum(vals) / len(vals)))
