@@ -15,7 +15,7 @@
 
 namespace admm {
 
-__device__ const double d_log_table[kLogPieces][4] = {ADMM_LOG_TABLE};
+__device__ const LogPiece d_log_table[kLogPieces] = {ADMM_LOG_TABLE};
 
 struct EdgeArgs {
   int E, V, k;
@@ -45,13 +45,11 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
   constexpr int LD = KP + 1;                    // padded row of the k x k scratch
   __shared__ float s_ep[GPB][KP * LD];
   __shared__ float s_np[GPB][2 * KP];
-  __shared__ float s_lmu[GPB][2 * KP];
+  __shared__ float s_lmu[GPB][KP];  // log mu of the first endpoint (every lane reads every entry)
   __shared__ float s_buf[GPB][KP];
-  __shared__ float s_m12[GPB][KP];
-  __shared__ float s_m21[GPB][KP];
-  __shared__ __attribute__((aligned(16))) double s_log[kLogPieces][4];
-  static_assert(kLogPieces * 2 == kEdgeBlock, "one 16-byte half row of the table per thread");
-  reinterpret_cast<double2 *>(&s_log[0][0])[threadIdx.x] = reinterpret_cast<const double2 *>(&d_log_table[0][0])[threadIdx.x];
+  __shared__ LogPiece s_log[kLogPieces];
+  static_assert(kLogPieces * 2 == kEdgeBlock, "half a piece of the table per thread");
+  reinterpret_cast<double *>(s_log)[threadIdx.x] = reinterpret_cast<const double *>(d_log_table)[threadIdx.x];
   __syncthreads();
 
   const int grp = threadIdx.x / KP;
@@ -79,6 +77,7 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
   // node vectors: UpdateLambda, AdjustPotentials, UpdateMu, node derivatives
   // and node potentials (Tree.cpp:64-73, 84-86, 48-51, 120-122, 141-143, 157-160)
   float pot_h[2];
+  float lmu2 = 0.0f;  // log mu of the second endpoint, this lane's entry
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     const int v = p.edgeList[2 * e + h];
@@ -99,7 +98,8 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
     float val = xnode + pp * nd;
     val = pp_pow2 ? val * inv_pp : val / pp;
     np[h * KP + i] = 0.0f - val;
-    lmu[h * KP + i] = lv;
+    if (h == 0) lmu[i] = lv;
+    else lmu2 = lv;
   }
   edge_lds_fence();
 
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
         const float mue = mue_b[u], pe = pe_b[u];
         const float muec = ((double)mue <= 0.0) ? EPS : mue;
         float ed = (float)(((double)lmu[a] - edge_log((double)muec, s_log)) + 1.0);
-        ed = ed + lmu[KP + i];
+        ed = ed + lmu2;
         const float xe = rho * pe;
         float val = xe + pp * ed;
         val = pp_pow2 ? val * inv_pp : val / pp;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
   edge_lds_fence();
   float sum = 0.0f;
   for (int j = 0; j < k; j++) sum += buf[j];
-  s_m12[grp][i] = acc / sum;
+  const float m12 = acc / sum;
   edge_lds_fence();
 
   // message 2 -> 1 (Tree.cpp:212-229): lane a sums over b
@@ -155,18 +155,18 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
   edge_lds_fence();
   sum = 0.0f;
   for (int j = 0; j < k; j++) sum += buf[j];
-  s_m21[grp][i] = acc / sum;
+  const float m21 = acc / sum;
   edge_lds_fence();
 
   // node marginals (Tree.cpp:236-254)
-  float t1 = (float)(exp((double)np[i]) * (double)s_m21[grp][i]);
+  float t1 = (float)(exp((double)np[i]) * (double)m21);
   buf[i] = t1;
   edge_lds_fence();
   sum = 0.0f;
   for (int j = 0; j < k; j++) sum += buf[j];
   const float mu1 = t1 / sum;
   edge_lds_fence();
-  float t2 = (float)(exp((double)np[KP + i]) * (double)s_m12[grp][i]);
+  float t2 = (float)(exp((double)np[KP + i]) * (double)m12);
   buf[i] = t2;
   edge_lds_fence();
   sum = 0.0f;
@@ -253,8 +253,8 @@ __global__ __launch_bounds__(1024) void edge_objective_sum_kernel(double *__rest
 // The solve's logarithm on a list of values (accuracy tests).
 __global__ __launch_bounds__(kEdgeBlock) void edge_log_values_kernel(double *__restrict__ y, const double *__restrict__ x,
                                                                      long long n) {
-  __shared__ __attribute__((aligned(16))) double s_log[kLogPieces][4];
-  reinterpret_cast<double2 *>(&s_log[0][0])[threadIdx.x] = reinterpret_cast<const double2 *>(&d_log_table[0][0])[threadIdx.x];
+  __shared__ LogPiece s_log[kLogPieces];
+  reinterpret_cast<double *>(s_log)[threadIdx.x] = reinterpret_cast<const double *>(d_log_table)[threadIdx.x];
   __syncthreads();
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x)
     y[idx] = edge_log(x[idx], s_log);

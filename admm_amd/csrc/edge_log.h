@@ -29,10 +29,15 @@
 namespace admm {
 
 constexpr int kLogPieces = 128;
-// {1 / c, -log(1 / c) high, low, unused}: 32 bytes per piece, read as two 16-byte halves
-static const double kLogTableHost[kLogPieces][4] = {ADMM_LOG_TABLE};
+// 16 bytes per piece, one read: -log(1 / c) as a binary64 high part and a binary32 low part, and
+// 1 / c in binary32 (the logarithm is that of the rounded value, so nothing is lost by it)
+struct __attribute__((aligned(16))) LogPiece {
+  double logc_hi;
+  float invc, logc_lo;
+};
+static const LogPiece kLogTableHost[kLogPieces] = {ADMM_LOG_TABLE};
 
-ADMM_LOG_FN double edge_log(double x, const double (*tab)[4]) {
+ADMM_LOG_FN double edge_log(double x, const LogPiece *tab) {
   const unsigned long long ix = __builtin_bit_cast(unsigned long long, x);
   const unsigned hx = (unsigned)(ix >> 32), lx = (unsigned)ix;
   const unsigned tmp = hx - 0x3fe60000u;
@@ -40,7 +45,8 @@ ADMM_LOG_FN double edge_log(double x, const double (*tab)[4]) {
   const int k = (int)tmp >> 20;
   const unsigned hz = hx - (tmp & 0xfff00000u);
   const double z = __builtin_bit_cast(double, ((unsigned long long)hz << 32) | lx);
-  const double invc = tab[i][0], lchi = tab[i][1], lclo = tab[i][2];
+  const LogPiece piece = tab[i];
+  const double invc = (double)piece.invc, lchi = piece.logc_hi, lclo = (double)piece.logc_lo;
   const double r = __builtin_fma(z, invc, -1.0);
   const double kd = (double)k;
   const double w = __builtin_fma(kd, ADMM_LOG_LN2_HI, lchi);  // exact
