@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "edge_log.h"
 
 namespace admm {
@@ -107,29 +109,34 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
   // of the table at a time: their loads leave together, so a wavefront waits for memory once per
   // batch and not once per row
   constexpr int kLoadAhead = 8;
-  for (int a0 = 0; a0 < k; a0 += kLoadAhead) {
-    float mue_b[kLoadAhead], pe_b[kLoadAhead];
+  auto derivatives = [&](auto pow2_c) {
+    constexpr bool POW2 = decltype(pow2_c)::value;  // the branch on it stays outside the loop
+    for (int a0 = 0; a0 < k; a0 += kLoadAhead) {
+      float mue_b[kLoadAhead], pe_b[kLoadAhead];
 #pragma unroll
-    for (int u = 0; u < kLoadAhead; u++) {
-      const bool ok = iv && a0 + u < k;
-      mue_b[u] = ok ? p.mu_edge[e * k2 + (a0 + u) * k + i] : 1.0f;
-      pe_b[u] = ok ? p.pot_edge[e * k2 + (a0 + u) * k + i] : 0.0f;
-    }
+      for (int u = 0; u < kLoadAhead; u++) {
+        const bool ok = iv && a0 + u < k;
+        mue_b[u] = ok ? p.mu_edge[e * k2 + (a0 + u) * k + i] : 1.0f;
+        pe_b[u] = ok ? p.pot_edge[e * k2 + (a0 + u) * k + i] : 0.0f;
+      }
 #pragma unroll
-    for (int u = 0; u < kLoadAhead; u++) {
-      const int a = a0 + u;
-      if (a < k) {
-        const float mue = mue_b[u], pe = pe_b[u];
-        const float muec = ((double)mue <= 0.0) ? EPS : mue;
-        float ed = (float)(((double)lmu[a] - edge_log((double)muec, s_log)) + 1.0);
-        ed = ed + lmu2;
-        const float xe = rho * pe;
-        float val = xe + pp * ed;
-        val = pp_pow2 ? val * inv_pp : val / pp;
-        ep[a * LD + i] = 0.0f - val;
+      for (int u = 0; u < kLoadAhead; u++) {
+        const int a = a0 + u;
+        if (a < k) {
+          const float mue = mue_b[u], pe = pe_b[u];
+          const float muec = ((double)mue <= 0.0) ? EPS : mue;
+          float ed = (float)(((double)lmu[a] - edge_log((double)muec, s_log)) + 1.0);
+          ed = ed + lmu2;
+          const float xe = rho * pe;
+          float val = xe + pp * ed;
+          val = POW2 ? val * inv_pp : val / pp;
+          ep[a * LD + i] = 0.0f - val;
+        }
       }
     }
-  }
+  };
+  if (pp_pow2) derivatives(std::true_type{});
+  else derivatives(std::false_type{});
   edge_lds_fence();
 
   // message 1 -> 2 (Tree.cpp:191-205): lane b sums over a
@@ -186,9 +193,21 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
     ep[i * LD + b] = ex;
     acc = acc + ex;
   }
+  // mu1 * ex / acc (Tree.cpp:271) for every b with one reciprocal: the binary64 product of
+  // mu1 * ex (rounded to binary32 as the reference's is) with the correctly rounded 1 / acc is
+  // within 2^-52 of the quotient, and the quotient of two binary32 values is at least 2^-50
+  // away (relatively) from every point where rounding to binary32 changes, unless it is exactly
+  // representable - so rounding the product gives the division's result.  Below the normal range
+  // a quotient can be an exact tie between two subnormal values, which the product may miss: a
+  // subnormal result is divided again, the slow way.
+  const double racc = 1.0 / (double)acc;
+  const bool acc_nz = acc != 0.0f;
   for (int b = 0; b < k; b++) {
     const float ex = ep[i * LD + b];
-    ep[i * LD + b] = (acc != 0.0f) ? (mu1 * ex / acc) : 0.0f;
+    const float num = mu1 * ex;
+    float q = (float)((double)num * racc);
+    if (__builtin_amdgcn_classf(q, 0x90)) q = num / acc;  // either subnormal class
+    ep[i * LD + b] = acc_nz ? q : 0.0f;
   }
   edge_lds_fence();
   if (p.obj_part == nullptr) {

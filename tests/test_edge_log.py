@@ -42,6 +42,17 @@ def test_host_build_gives_the_committed_bits(host_program):
     assert np.count_nonzero(y.astype(np.float32) != ref.astype(np.float32)) <= 2
 
 
+def test_division_by_the_rounded_reciprocal_is_the_division(tmp_path):
+    """The solve's mu1 * ex / acc (Tree.cpp:271) as a binary64 product with 1 / acc, redone as a
+    division when the result is subnormal: bit for bit the binary32 division, on random pairs and
+    on pairs built next to rounding boundaries, the overflow and the underflow thresholds."""
+    exe = str(tmp_path / "check_recip_div")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tools", "check_recip_div.cpp")])
+    out = subprocess.run([exe, "20000000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert "20000000 pairs: 0 results differ" in out.stdout and "DIFFERENT" not in out.stdout
+
+
 @pytest.mark.gpu
 def test_device_gives_the_host_builds_bits():
     import ctypes as C
