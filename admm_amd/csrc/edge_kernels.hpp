@@ -67,6 +67,7 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
   // x / penaltyPrime (Tree.cpp:160, 172) for a power of two (1 by default) is x * (1 / penaltyPrime):
   // the same real number, so the same rounding, without the division's dozen instructions
   const float inv_pp = 1.0f / pp;
+  const double rpp = 1.0 / (double)pp;
   const bool pp_pow2 = (__float_as_uint(pp) & 0x807fffffu) == 0 && (__float_as_uint(pp) >> 23) != 0 &&
                        (__float_as_uint(pp) >> 23) != 255 && (__float_as_uint(inv_pp) & 0x7f800000u) != 0 &&
                        inv_pp * pp == 1.0f;
@@ -129,7 +130,13 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
           ed = ed + lmu2;
           const float xe = rho * pe;
           float val = xe + pp * ed;
-          val = POW2 ? val * inv_pp : val / pp;
+          if constexpr (POW2) {
+            val = val * inv_pp;
+          } else {  // as for the edge marginals below: product with the rounded reciprocal
+            const float num = val;
+            val = (float)((double)num * rpp);
+            if (__builtin_amdgcn_classf(val, 0x90)) val = num / pp;
+          }
           ep[a * LD + i] = 0.0f - val;
         }
       }

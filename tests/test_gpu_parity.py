@@ -315,6 +315,32 @@ def test_edge_against_oracle_per_edge_tables(R, C, k):
     g.close()
 
 
+@pytest.mark.parametrize("penalty,prime,rho", [(0.5, 1.0, 1.0), (0.7, 0.3, 1.0), (1.5, 2.0, 0.5), (0.25, 0.75, 2.0), (0.1, 0.5, 1.0)])
+@pytest.mark.parametrize("k", [4, 16, 32])
+def test_edge_penalties(penalty, prime, rho, k):
+    """Other penalties than the drivers' (Grid.cpp:79-80 are the class defaults, the last case):
+    x / penaltyPrime is a multiplication for a power of two and a product with the rounded
+    reciprocal otherwise (Tree.cpp:160, 172)."""
+    import admm_amd as A
+    from oracle import oracle as O
+    R, C = 6, 7
+    un, _ = O.synth_problem(R, C, k, 77, "potts")
+    el = O.grid_edges(R, C)
+    ep, _ = O.lcg_fill(4242, (el.size // 2) * k * k)
+    o = O.EdgeOracle(R * C, el, k, un, ep, penalty=penalty, penalty_prime=prime, rho=rho); o.init()
+    g = A.Grid()
+    g.SetPartitioner(A.EDGE); g.SetPenalties(penalty, prime); g.SetRhoEdge(rho)
+    g.SetGlobalInfo(R, C, k); g.Load(un, ep, per_edge=True); g.InitOptimization()
+    for it in range(10):
+        o.compute(); o.update(); _step(g)
+        a, b = o.objective(), g.ComputeLinearObj()
+        assert abs(a - b) <= EDGE_RTOL * abs(a), it
+    st = o.state()
+    for which, n in ((0, "mu_node"), (3, "lambda_node"), (4, "mu_edge"), (2, "m_node")):
+        np.testing.assert_allclose(g.State(which), st[n], rtol=EDGE_RTOL, atol=1e-7, err_msg=n)
+    g.close()
+
+
 def test_edge_on_general_graph():
     import admm_amd as A
     gold = np.load(os.path.join(GOLD, "edge_graph7_k3.npz"))

@@ -50,6 +50,7 @@ int main(int argc, char **argv) {
         break;
     }
     if (b == 0.0f) continue;
+    if (u >> 63) a = -a;  // x / penaltyPrime has numerators of either sign
     const float want = a / b;
     long sl = 0;
     const float got = fast_div(a, b, &sl);
