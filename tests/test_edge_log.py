@@ -43,9 +43,10 @@ def test_host_build_gives_the_committed_bits(host_program):
 
 
 def test_division_by_the_rounded_reciprocal_is_the_division(tmp_path):
-    """The solve's mu1 * ex / acc (Tree.cpp:271) as a binary64 product with 1 / acc, redone as a
-    division when the result is subnormal: bit for bit the binary32 division, on random pairs and
-    on pairs built next to rounding boundaries, the overflow and the underflow thresholds."""
+    """The solve's mu1 * ex / acc (Tree.cpp:271) as a binary64 product with 1 / acc and one
+    residual step: bit for bit the binary32 division, on random pairs, on pairs built next to
+    rounding boundaries, around the overflow and the underflow thresholds and on exact ties
+    between two subnormal results."""
     exe = str(tmp_path / "check_recip_div")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tools", "check_recip_div.cpp")])
     out = subprocess.run([exe, "20000000"], capture_output=True, text=True)
