@@ -271,7 +271,14 @@ __global__ __launch_bounds__(1024) void edge_objective_sum_kernel(double *__rest
                                                                    const double *__restrict__ part, int n) {
   __shared__ double s_red[16];
   double acc = 0.0;
-  for (int q = threadIdx.x; q < n; q += 1024) acc += part[q];
+  // eight loads in flight per thread (a thread has up to 64 terms at 512 x 512, k = 32)
+  for (int q0 = threadIdx.x; q0 < n; q0 += 8 * 1024) {
+    double t[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) t[u] = q0 + u * 1024 < n ? part[q0 + u * 1024] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc += t[u];
+  }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
@@ -293,6 +300,25 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_log_values_kernel(double *__r
     y[idx] = edge_log(x[idx], s_log);
 }
 
+// Entry l of the copies inc[b .. en) of a vertex, added in that (edge-list) order.  Four copies at
+// a time (a grid vertex has at most four): their positions, then their values, leave together.
+__device__ __forceinline__ float edge_sum_copies(const float *__restrict__ mu_node, const int *__restrict__ inc,
+                                                 int b, int en, int k, int l) {
+  float s = 0.0f;
+  for (int q0 = b; q0 < en; q0 += 4) {
+    int pos[4];
+    float val[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) pos[u] = inc[min(q0 + u, en - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; u++) val[u] = mu_node[(long long)pos[u] * k + l];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (q0 + u < en) s += val[u];
+  }
+  return s;
+}
+
 // Consensus (Grid.cpp:144-148 + Tree.cpp:244,253 + Grid.cpp:163-181): the
 // copies of vertex v are summed in edge-list order, as the serial loop of
 // Grid::Compute adds them, then divided by the copy count.  inc holds, per
@@ -305,8 +331,7 @@ __global__ void edge_consensus_kernel(float *__restrict__ m_vert, const float *_
        idx += (long long)gridDim.x * blockDim.x) {
     const int v = (int)(idx / k), l = (int)(idx % k);
     const int b = inc_off[v], en = inc_off[v + 1];
-    float s = 0.0f;
-    for (int q = b; q < en; q++) s += mu_node[(long long)inc[q] * k + l];
+    const float s = edge_sum_copies(mu_node, inc, b, en, k, l);
     const int cnt = en - b;
     // a vertex no edge touches (possible in a caller's graph; the reference's vertex
     // sets hold endpoints only, Grid.cpp:815-856) keeps the uniform vector admm_init wrote
@@ -323,9 +348,7 @@ __global__ void edge_partial_kernel(float *__restrict__ m_part, const float *__r
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     const int v = (int)(idx / k), l = (int)(idx % k);
-    float s = 0.0f;
-    for (int q = inc_off[v]; q < inc_off[v + 1]; q++) s += mu_node[(long long)inc[q] * k + l];
-    m_part[idx] = s;
+    m_part[idx] = edge_sum_copies(mu_node, inc, inc_off[v], inc_off[v + 1], k, l);
   }
 }
 
