@@ -1570,6 +1570,7 @@ int admm_init(admm_ctx *c) {
   if (!is_chain(c)) {
     const long long E = c->E, V = c->V, k = d.k, k2 = k * k;
     const float inv_k2 = (float)(1.0 / (double)(float)(d.k * d.k));
+    c->edge_obj_n = 0;  // the last solve's objective terms belong to the state this call replaces
     if (E > 0) {
       hipLaunchKernelGGL(edge_init_node_kernel, dim3(grid_for(E * 2 * k, 256)), dim3(256), 0, s, c->d_pot_node,
                          c->d_mu_node, c->d_lam_node, c->d_vert_pot, c->d_edges, c->d_inc_off, (int)E, (int)k, d.rho, c->inv_k);

@@ -403,6 +403,28 @@ def test_edge_objective_summed_by_the_solve_equals_the_separate_pass(R, C, k, mo
     gs.close(); gf.close()
 
 
+def test_edge_objective_after_a_second_init():
+    """admm_init after solves starts over: the objective asked for before the next solve is the
+    initial state's, not the sum the last solve left behind."""
+    from oracle import oracle as O
+    R, C, k = 9, 8, 8
+    un, W = O.synth_problem(R, C, k, 3, "potts")
+    g = _edge_grid(R, C, k, un, W)
+    first = g.ComputeLinearObj()
+    for _ in range(3):
+        _step(g)
+    later = g.ComputeLinearObj()
+    from admm_amd._lib import lib
+    g._ck(lib.admm_init(g._h))
+    again = g.ComputeLinearObj()
+    assert again == first and again != later
+    _step(g)
+    o = O.EdgeOracle(R * C, O.grid_edges(R, C), k, un, np.tile(W.reshape(-1), O.grid_edges(R, C).size // 2)); o.init()
+    o.compute(); o.update()
+    assert abs(g.ComputeLinearObj() - o.objective()) <= EDGE_RTOL * abs(o.objective())
+    g.close()
+
+
 # ---------------------------------------------------------------- call-order errors
 
 def test_call_order_errors():
