@@ -125,8 +125,10 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
 
   // edge derivatives and potentials (Tree.cpp:123-133, 144-150, 98-99, 169-172), kLoadAhead rows
   // of the table at a time: their loads leave together, so a wavefront waits for memory once per
-  // batch and not once per row
+  // batch and not once per row.  Lane b walks column b, which is also what message 1 -> 2
+  // (Tree.cpp:191-205: lane b sums over a) reads: its terms are added as the column is formed.
   constexpr int kLoadAhead = 8;
+  float acc = 0.0f;
   auto derivatives = [&](auto pow2_c) {
     constexpr bool POW2 = decltype(pow2_c)::value;  // the branch on it stays outside the loop
     for (int a0 = 0; a0 < k; a0 += kLoadAhead) {
@@ -152,7 +154,10 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
           } else {
             val = edge_divide(val, (double)pp, rpp);
           }
-          ep[a * LD + i] = 0.0f - val;
+          const float epv = 0.0f - val;
+          ep[a * LD + i] = epv;
+          const float c = epv + np[a];
+          acc = (float)((double)acc + exp((double)c));
         }
       }
     }
@@ -160,13 +165,6 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
   if (pp_pow2) derivatives(std::true_type{});
   else derivatives(std::false_type{});
   edge_lds_fence();
-
-  // message 1 -> 2 (Tree.cpp:191-205): lane b sums over a
-  float acc = 0.0f;
-  for (int a = 0; a < k; a++) {
-    const float c = ep[a * LD + i] + np[a];
-    acc = (float)((double)acc + exp((double)c));
-  }
   buf[i] = acc;
   edge_lds_fence();
   float sum = 0.0f;
@@ -174,11 +172,20 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
   const float m12 = acc / sum;
   edge_lds_fence();
 
-  // message 2 -> 1 (Tree.cpp:212-229): lane a sums over b
+  // message 2 -> 1 (Tree.cpp:212-229): lane a sums over b; the same walk over row a forms the
+  // exponentials of the edge marginal and their sum (Tree.cpp:256-268), which need no message
   acc = 0.0f;
+  float row_sum = 0.0f;
+  const float np_own = np[i];
   for (int b = 0; b < k; b++) {
-    const float c = ep[i * LD + b] + np[KP + b];
+    const float epv = ep[i * LD + b], n2 = np[KP + b];
+    const float c = epv + n2;
     acc = (float)((double)acc + exp((double)c));
+    float q = epv + np_own;
+    q = q + n2;
+    const float ex = (float)exp((double)q);
+    ep[i * LD + b] = ex;
+    row_sum = row_sum + ex;
   }
   buf[i] = acc;
   edge_lds_fence();
@@ -206,18 +213,10 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
     p.mu_node[e * 2 * k + k + i] = mu2;
   }
 
-  // edge marginal (Tree.cpp:256-273): lane a owns row a
-  acc = 0.0f;
-  for (int b = 0; b < k; b++) {
-    float q = ep[i * LD + b] + np[i];
-    q = q + np[KP + b];
-    const float ex = (float)exp((double)q);
-    ep[i * LD + b] = ex;
-    acc = acc + ex;
-  }
-  // mu1 * ex / acc (Tree.cpp:271) for every b with one reciprocal (edge_divide)
-  const double accd = (double)acc, racc = 1.0 / accd;
-  const bool acc_nz = acc != 0.0f;
+  // edge marginal (Tree.cpp:269-273): lane a owns row a; mu1 * ex / sum for every b with one
+  // reciprocal (edge_divide)
+  const double accd = (double)row_sum, racc = 1.0 / accd;
+  const bool acc_nz = row_sum != 0.0f;
   for (int b = 0; b < k; b++) {
     const float ex = ep[i * LD + b];
     const float q = edge_divide(mu1 * ex, accd, racc);
