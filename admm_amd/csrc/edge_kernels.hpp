@@ -129,8 +129,10 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
   // (Tree.cpp:191-205: lane b sums over a) reads: its terms are added as the column is formed.
   constexpr int kLoadAhead = 8;
   float acc = 0.0f;
-  auto derivatives = [&](auto pow2_c) {
-    constexpr bool POW2 = decltype(pow2_c)::value;  // the branch on it stays outside the loop
+  // how x / penaltyPrime is formed: 0 any value, 1 a power of two, 2 penaltyPrime = rho = 1 (the
+  // drivers' values, admm.cpp:44-47: the multiplications by 1 are left out, x * 1 being x)
+  auto derivatives = [&](auto how_c) {
+    constexpr int HOW = decltype(how_c)::value;  // the branch on it stays outside the loop
     for (int a0 = 0; a0 < k; a0 += kLoadAhead) {
       float mue_b[kLoadAhead], pe_b[kLoadAhead];
 #pragma unroll
@@ -147,12 +149,14 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
           const float muec = ((double)mue <= 0.0) ? EPS : mue;
           float ed = (float)(((double)lmu[a] - edge_log((double)muec, s_log)) + 1.0);
           ed = ed + lmu2;
-          const float xe = rho * pe;
-          float val = xe + pp * ed;
-          if constexpr (POW2) {
-            val = val * inv_pp;
+          float val;
+          if constexpr (HOW == 2) {
+            val = pe + ed;
           } else {
-            val = edge_divide(val, (double)pp, rpp);
+            const float xe = rho * pe;
+            val = xe + pp * ed;
+            if constexpr (HOW == 1) val = val * inv_pp;
+            else val = edge_divide(val, (double)pp, rpp);
           }
           const float epv = 0.0f - val;
           ep[a * LD + i] = epv;
@@ -162,8 +166,9 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
       }
     }
   };
-  if (pp_pow2) derivatives(std::true_type{});
-  else derivatives(std::false_type{});
+  if (pp == 1.0f && rho == 1.0f) derivatives(std::integral_constant<int, 2>{});
+  else if (pp_pow2) derivatives(std::integral_constant<int, 1>{});
+  else derivatives(std::integral_constant<int, 0>{});
   edge_lds_fence();
   buf[i] = acc;
   edge_lds_fence();
@@ -217,10 +222,20 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
   // reciprocal (edge_divide)
   const double accd = (double)row_sum, racc = 1.0 / accd;
   const bool acc_nz = row_sum != 0.0f;
-  for (int b = 0; b < k; b++) {
-    const float ex = ep[i * LD + b];
-    const float q = edge_divide(mu1 * ex, accd, racc);
-    ep[i * LD + b] = acc_nz ? q : 0.0f;
+  // a positive finite sum in every lane of the wavefront (then no exponential of the row is
+  // infinite either): the residual step cannot meet an infinity, and its guard is left out
+  if (__builtin_amdgcn_ballot_w64(!__builtin_amdgcn_classf(row_sum, 0x180)) == 0) {  // +normal or +subnormal
+    for (int b = 0; b < k; b++) {
+      const double n = (double)(mu1 * ep[i * LD + b]);
+      const double q0 = n * racc;
+      ep[i * LD + b] = (float)__builtin_fma(__builtin_fma(-q0, accd, n), racc, q0);
+    }
+  } else {
+    for (int b = 0; b < k; b++) {
+      const float ex = ep[i * LD + b];
+      const float q = edge_divide(mu1 * ex, accd, racc);
+      ep[i * LD + b] = acc_nz ? q : 0.0f;
+    }
   }
   edge_lds_fence();
   if (p.obj_part == nullptr) {
