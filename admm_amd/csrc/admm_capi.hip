@@ -31,27 +31,31 @@ namespace {
 
 thread_local std::string g_create_error;
 
-// Where each device keeps its copy of `scratch` (null: not asked yet, or the
-// query failed, see g_scratch_err).
+// Where each device keeps its copy of `scratch` (null: not asked yet, or the last
+// query failed, see g_scratch_err).  Read and written under g_scratch_mu only.
 constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mu;
 int32_t *g_scratch_ptr[kMaxDevices] = {};
-bool g_scratch_asked[kMaxDevices] = {};
 std::string g_scratch_err[kMaxDevices];
 
-// Once per device, with that device current.
-void scratch_setup(int device) {
-  if (device < 0 || device >= kMaxDevices) return;
+// The address of `device`'s copy, asked for once per device with that device current
+// (a query that failed is made again by the next caller).  Null with *why set on failure.
+int32_t *scratch_for(int device, std::string *why) {
+  if (device < 0 || device >= kMaxDevices) {
+    if (why) *why = "device ordinal out of range";
+    return nullptr;
+  }
   std::lock_guard<std::mutex> lock(g_scratch_mu);
-  if (g_scratch_asked[device]) return;
-  g_scratch_asked[device] = true;
+  if (g_scratch_ptr[device]) return g_scratch_ptr[device];
   int32_t *ptr = nullptr;
   const hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
   if (e != hipSuccess || !ptr) {
     g_scratch_err[device] = std::string("hipGetSymbolAddress(scratch) failed: ") + hipGetErrorString(e);
-    return;
+    if (why) *why = g_scratch_err[device];
+    return nullptr;
   }
   g_scratch_ptr[device] = ptr;
+  return ptr;
 }
 
 struct Strip {
@@ -282,8 +286,8 @@ int dev_alloc(admm_ctx *c, T **p, size_t n) {
   return ADMM_OK;
 }
 
-// Device staging of at least `bytes` for a download call; kept by the context,
-// so only a call that needs more than any call before it allocates.
+// Device staging of at least `bytes` for a download call; up to kStageKeepBytes it is
+// kept by the context, so only a call that needs more than the calls before it allocates.
 int stage_buf(admm_ctx *c, void **p, size_t bytes) {
   if (bytes > c->stage_bytes) {
     if (c->d_stage) {
@@ -302,6 +306,26 @@ int stage_buf(admm_ctx *c, void **p, size_t bytes) {
   *p = c->d_stage;
   return ADMM_OK;
 }
+
+// The staging is kept between calls only while it is small: a download of the consensus
+// vectors or of widened state of a large grid takes hundreds of megabytes, which go back
+// to the device when the call that asked for them returns (every download call waits for
+// its copy, so nothing is in flight then).
+constexpr size_t kStageKeepBytes = 64u << 20;
+struct StageRelease {
+  admm_ctx *c;
+  explicit StageRelease(admm_ctx *ctx) : c(ctx) {}
+  StageRelease(const StageRelease &) = delete;
+  StageRelease &operator=(const StageRelease &) = delete;
+  ~StageRelease() {
+    if (c && c->d_stage && c->stage_bytes > kStageKeepBytes) {
+      (void)hipStreamSynchronize(c->stream);
+      (void)hipFree(c->d_stage);
+      c->d_stage = nullptr;
+      c->stage_bytes = 0;
+    }
+  }
+};
 
 // Host -> device on the context's own stream, complete on return.  (The stream does
 // not synchronise with the null stream, so nothing the kernels read goes through that one.)
@@ -813,6 +837,15 @@ int chain_sweep(admm_ctx *c, bool dual) {
 }
 
 int chain_sweep_launch(admm_ctx *c, bool dual) {
+  // The queued objective sums move into this launch's arguments; if the launch then fails
+  // they go back on the queue, so that a later read still sums them.
+  const std::vector<admm_ctx::RedJob> red_q_before = c->red_q;
+  const int swept_before = c->swept_slot;
+  bool moved_q = false;
+  auto give_back = [&](int rc) {
+    if (rc && moved_q) { c->red_q = red_q_before; c->swept_slot = swept_before; }
+    return rc;
+  };
   ChainArgs a{};
   a.nseg = 2;
   fill_seg_rows(c, a.seg[0], dual);
@@ -856,12 +889,13 @@ int chain_sweep_launch(admm_ctx *c, bool dual) {
     a.red_jobs = (int)c->red_q.size();
     for (int j = 0; j < a.red_jobs; j++) { a.red_dst[j] = c->red_q[j].dst; a.red_part[j] = c->red_q[j].part; a.red_n[j] = c->red_q[j].n; }
     c->red_q.clear();
+    moved_q = true;
   }
   if (dual && c->lam16) {
     // the dual evaluation reads binary32 multipliers
     const float *fr = nullptr, *fc = nullptr;
     const int rc = lam16_widen(c, &fr, &fc);
-    if (rc) return rc;
+    if (rc) return give_back(rc);
     a.seg[0].lam = fr;
     a.seg[1].lam = fc;
   }
@@ -873,7 +907,7 @@ int chain_sweep_launch(admm_ctx *c, bool dual) {
     HIP_TRY(c, hipMemset(d_st, 0, nw * 4 * sizeof(unsigned long long)));
     a.stamps = d_st;
     int rc = launch_sweep<false>(c, a, sh);
-    if (rc) return rc;
+    if (rc) return give_back(rc);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     std::vector<unsigned long long> h(nw * 4);
     HIP_TRY(c, hipMemcpy(h.data(), d_st, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -960,7 +994,7 @@ int chain_sweep_launch(admm_ctx *c, bool dual) {
     rc = dual ? launch_sweep<true>(c, a, sh) : launch_sweep<false>(c, a, sh);
   }
   if (!rc && !dual) sweep_outputs_current(c, a);
-  return rc;
+  return give_back(rc);
 }
 
 template <typename TB>
@@ -1234,7 +1268,7 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
     }                                                                            \
   } while (0)
   if (hipSetDevice(d.device) != hipSuccess) { c->err = "hipSetDevice failed"; return bail(ADMM_E_HIP); }
-  scratch_setup(d.device);  // (a failure only disables admm_download_labels_static on this device)
+  (void)scratch_for(d.device, nullptr);  // (a failure only disables admm_download_labels_static until a later query succeeds)
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(ADMM_E_HIP); }
 
   if (d.solver == ADMM_SOLVER_EDGE_BETHE) {
@@ -2514,6 +2548,7 @@ static int decode_labels_into(admm_ctx *c, int *stage, int32_t *labels, long lon
 int admm_download_labels(admm_ctx *c, int32_t *labels) {
   int rc = check_ctx(c);
   if (rc) return rc;
+  StageRelease release(c);
   if (!is_chain(c)) return fail(c, ADMM_E_STATE, "the edge solver decodes no labels");
   if (!c->inited) return fail(c, ADMM_E_STATE, "download before admm_init");
   if (!labels) return fail(c, ADMM_E_ARG, "null output");
@@ -2535,10 +2570,10 @@ int admm_download_labels_static(admm_ctx *c, int32_t *labels) {
     return fail(c, ADMM_E_ARG, "admm_download_labels_static: this strip has %lld labels, the static staging holds %lld; use admm_download_labels",
                 total, (long long)ADMM_STATIC_LABELS_MAX);
   const int dev = c->d.device;
-  int32_t *stage = (dev >= 0 && dev < kMaxDevices) ? g_scratch_ptr[dev] : nullptr;
+  std::string why;
+  int32_t *stage = scratch_for(dev, &why);  // (check_ctx made the context's device current)
   if (!stage)
-    return fail(c, ADMM_E_HIP, "admm_download_labels_static: no static staging on device %d (%s)", dev,
-                (dev >= 0 && dev < kMaxDevices && !g_scratch_err[dev].empty()) ? g_scratch_err[dev].c_str() : "device ordinal out of range");
+    return fail(c, ADMM_E_HIP, "admm_download_labels_static: no static staging on device %d (%s)", dev, why.c_str());
   if (total == 0) return ADMM_OK;
   // the decode kernel writes every element it later copies out: nothing of an
   // earlier call's contents is read
@@ -2548,6 +2583,7 @@ int admm_download_labels_static(admm_ctx *c, int32_t *labels) {
 int admm_download_consensus(admm_ctx *c, float *out) {
   int rc = check_ctx(c);
   if (rc) return rc;
+  StageRelease release(c);
   if (!c->inited) return fail(c, ADMM_E_STATE, "download before admm_init");
   if (!out) return fail(c, ADMM_E_ARG, "null output");
   if (!is_chain(c)) {
@@ -2590,6 +2626,7 @@ size_t admm_state_size(const admm_ctx *c, int which) {
 int admm_download_state(admm_ctx *c, int which, float *out) {
   int rc = check_ctx(c);
   if (rc) return rc;
+  StageRelease release(c);
   if (!c->inited) return fail(c, ADMM_E_STATE, "download before admm_init");
   if (!out) return fail(c, ADMM_E_ARG, "null output");
   const size_t n = admm_state_size(c, which);
@@ -2675,6 +2712,19 @@ int admm_comm_init(admm_ctx *c, const void *id) {
     return fail(c, ADMM_E_COMM, "ncclCommInitRank(nranks=%d, rank=%d) failed: %s", c->d.nranks, c->d.rank, ncclGetErrorString(r));
   }
   c->comm = comm;
+  return ADMM_OK;
+}
+
+int admm_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+    return fail(nullptr, ADMM_E_ARG, "device %d out of range (%d devices)", device, ndev);
+  size_t f = 0, t = 0;
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipMemGetInfo(&f, &t);
+  if (e != hipSuccess) return fail(nullptr, ADMM_E_HIP, "hipMemGetInfo failed: %s", hipGetErrorString(e));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
   return ADMM_OK;
 }
 

@@ -217,6 +217,7 @@ void Grid::InitOptimization() {
 void Grid::Compute() { check(admm_compute(ctx), "admm_compute"); }
 void Grid::Communicate() { check(admm_communicate(ctx), "admm_communicate"); }
 void Grid::Update() { check(admm_update(ctx), "admm_update"); }
+void Grid::Synchronize() { check(admm_synchronize(ctx), "admm_synchronize"); }
 
 double Grid::ComputeLinearObj() {
   double v = 0.0;

@@ -85,6 +85,9 @@ class Grid : public GraphBase {
   void Update();
   double ComputeLinearObj();
   void FinalizeOptimization();
+  // Waits for everything this strip has queued on its device.  The reference's phases
+  // are synchronous; its PROFILE macro times them between barriers (admm.cpp:15-18).
+  void Synchronize();
 
   // chain solver extras (no counterpart in the reference)
   void Objective(double *primal, double *dual);

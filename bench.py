@@ -21,6 +21,35 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def _requested_gpus(argv):
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+def _self_launch():
+    """`python bench.py --gpus N` typed as it stands (the reference's equivalent is one
+    `mpiexec -n N` line, admm.cpp:27): start one process per GPU through
+    torch.distributed.run as CHILD processes and leave with the launcher's exit code.
+    This runs before the HIP library is loaded, so the parent never touches a GPU."""
+    import socket
+    import subprocess
+    n = _requested_gpus(sys.argv[1:])
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _requested_gpus(sys.argv[1:]) > 1:
+    _self_launch()
+
 # The HIP library comes first so that the process uses one HIP / RCCL runtime,
 # the one the library was built against.
 import admm_amd as A  # noqa: E402
@@ -33,6 +62,8 @@ WORKLOADS = {
     "2048x2048_k32_potts": (2048, 2048, 32, 1, "potts"),
     "512x512_k16_trunc_linear": (512, 512, 16, 1, "trunc_linear"),
     "1024x1024_k64_dense": (1024, 1024, 64, 1, "dense"),
+    # the headline grid with an arbitrary k x k table: the general min-plus kernel
+    "2048x2048_k32_dense": (2048, 2048, 32, 1, "dense"),
     "256x(256x256)_k8_potts": (256, 256, 8, 256, "potts"),
     "64x64_k4_potts": (64, 64, 4, 1, "potts"),
     # the reference's own algorithm (one tree per edge, Tree.cpp:112-274): secondary
@@ -178,10 +209,91 @@ def measured_traffic(workload, world, kernel):
     return None, None
 
 
+GOLDEN = os.path.join(ROOT, "tests", "golden", "bench_objectives.json")
+
+
+def golden_name(workload, penalty):
+    return workload if penalty == 0.5 else "%s_penalty%g" % (workload, penalty)
+
+
+def objective_check(workload, penalty, seed, first_it, linear, total_its=None, final=None, labels_sha=None):
+    """What the run left behind against the committed values of the same trajectory
+    (tests/golden/bench_objectives.json, written in the build container by
+    tests/golden/make_bench_objectives.py with the CPU oracle; nothing of the oracle runs
+    here).  linear[i] is the linear objective after iteration first_it + i (1-based);
+    final = (primal, linear, dual) after total_its iterations."""
+    try:
+        doc = json.load(open(GOLDEN))
+    except (OSError, ValueError):
+        return {"checked": False, "why": "tests/golden/bench_objectives.json is missing"}
+    case = doc.get(golden_name(workload, penalty))
+    if case is None or seed != case.get("seed"):
+        return {"checked": False, "why": "no committed trajectory for this workload, penalty and seed"}
+    gl = case["linear"]
+    n = max(0, min(len(linear), len(gl) - (first_it - 1)))
+    out = {"checked": n > 0, "source": "tests/golden/bench_objectives.json", "iterations_compared": n,
+           "first_iteration": first_it}
+    if n > 0:
+        exp = np.array(gl[first_it - 1:first_it - 1 + n])
+        got = np.array(linear[:n], dtype=np.float64)
+        rel = np.abs(got - exp) / np.abs(exp)
+        out["linear"] = {"expected_last": float(exp[-1]), "got_last": float(got[-1]), "rel_err": float(rel.max())}
+        out["rel_err"] = float(rel.max())
+    at = case["at"].get(str(total_its)) if total_its is not None else None
+    if at is not None and final is not None:
+        for name, got in zip(("primal", "linear", "dual"), final):
+            e = at[name]
+            r = abs(got - e) / abs(e)
+            out[name + "_at_%d" % total_its] = {"expected": e, "got": float(got), "rel_err": r}
+            out["rel_err"] = max(out.get("rel_err", 0.0), r)
+        if labels_sha is not None:
+            out["labels_bit_exact"] = (labels_sha == at["labels_sha256"])
+        out["checked"] = True
+    if out["checked"]:
+        out["ok"] = out["rel_err"] <= 1e-9 and out.get("labels_bit_exact", True)
+    return out
+
+
+def labels_sha256(g):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(g.Labels(), dtype="<i4").tobytes()).hexdigest()
+
+
+def quick_rate(workload, penalty, seed, steps=12, warmup=3):
+    """A short single-GPU run of another workload, for the `secondary` fields of the
+    headline line: the same step as the timed region of main()."""
+    rows, cols, k, batch, pairwise = WORKLOADS[workload]
+    g = A.Grid(rank=0, nprocs=1, device=0)
+    g.SetPartitioner(A.ROW)
+    g.SetPenalties(penalty, 1.0)
+    g.SetGlobalInfo(rows, cols, k, batch=batch)
+    g.Generate(seed=seed, pairwise=pairwise)
+    g.InitOptimization()
+    g._unary = None
+    for i in range(warmup):
+        g.Compute(); g.Communicate(); g.Update(); g.ObjectiveEnqueue(1 + i)
+    g.Synchronize()
+    g.ProfileReset(3)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        g.Compute(); g.Communicate(); g.Update(); g.ObjectiveEnqueue(1 + warmup + i)
+    g.Synchronize()
+    dt = time.perf_counter() - t0
+    kernel_ms, launches = g.ProfileRead()
+    g.ProfileReset(False)
+    linear = g.ObjectiveRead(1, warmup + steps)
+    out = {"workload": workload, "penalty": penalty, "value": steps / dt, "unit": "it/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": 1e3 * dt / steps, "kernel": g.SweepKernelName(), "ms_per_launch": kernel_ms,
+           "objective_check": objective_check(workload, penalty, seed, 1, linear)}
+    g.FinalizeOptimization()
+    g.close()
+    return out
+
+
 def make_grid(args, rank, nprocs, device, rows, cols, k, batch, pairwise, seed, edge):
     g = A.Grid(rank=rank, nprocs=nprocs, device=device)
     g.SetPartitioner(A.EDGE if edge else A.ROW)
-    g.SetPenalties(0.5, 1.0)  # admm.cpp:44
+    g.SetPenalties(args.penalty, 1.0)  # admm.cpp:44: 0.5, 1.0
     g.SetGlobalInfo(rows, cols, k, batch=batch)
     g.exchange = 0 if args.exchange == "labels" else 1
     g.Generate(seed=seed, pairwise=pairwise)
@@ -198,6 +310,12 @@ def main():
     ap.add_argument("--workload", default="2048x2048_k32_potts", choices=sorted(WORKLOADS))
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--penalty", type=float, default=0.5,
+                    help="ADMM penalty (admm.cpp:44 sets 0.5).  Half of it a power of two lets the chain solver keep its "
+                         "multipliers as integer counts; any other value runs the binary32 multiplier kernels")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="headline workload on one GPU: skip the short runs of the general-table kernel and of a "
+                         "penalty that is not a power of two, which are reported as `secondary`")
     ap.add_argument("--exchange", default="labels", choices=["labels", "dense"])
     ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "host"],
                     help="N > 1: RCCL send/recv inside admm_communicate, or labels staged through the host "
@@ -238,6 +356,7 @@ def main():
     grank = rank if nprocs_for_grid > 1 else 0
     g = make_grid(args, grank, nprocs_for_grid, device, rows, cols, k, my_batch, pairwise, args.seed + b0, edge)
     transport = "none"
+    done_its = 0  # iterations this context has run before the warm-up (the RCCL probe)
     if nprocs_for_grid > 1:
         transport = args.transport
         if transport in ("auto", "rccl"):
@@ -265,6 +384,7 @@ def main():
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag[0]) == 1:
                 transport = "rccl"
+                done_its = 1
             elif transport == "rccl":
                 sys.exit("RCCL failed and --transport rccl was requested")
             else:
@@ -295,9 +415,9 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
-    # HIP events around a sample of the Compute launches (every launch of a short run): the two
-    # records cost several microseconds of stream time each time
-    g.ProfileReset(max(1, min(8, args.steps // 12)))
+    # HIP events around a sample of the Compute launches (one in four of a 20-step run, every
+    # launch of a shorter one): the two records cost several microseconds of stream time each time
+    g.ProfileReset(max(1, min(8, args.steps // 5)))
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -312,16 +432,23 @@ def main():
 
     kernel_ms, launches = g.ProfileRead()
     g.ProfileReset(False)
+    linear = None
+    sha = None
     if edge:
         last = np.array([edge_obj[-1], edge_obj[-1], float("nan")], dtype=np.float64)
     else:
         linear = g.ObjectiveRead(1 + args.warmup, args.steps)
         primal, dual = g.Objective(dual=True)  # decoded energy and dual bound, evaluated once at the end
         last = np.array([primal, linear[-1], dual], dtype=np.float64)
+        if world == 1 and batch * rows * cols <= (1 << 25):
+            sha = labels_sha256(g)
     if dist is not None:
         import torch
         tt = torch.from_numpy(last)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)  # admm.cpp:95
+        if linear is not None:
+            tl = torch.from_numpy(linear)
+            dist.all_reduce(tl, op=dist.ReduceOp.SUM)
         sm = torch.tensor([kernel_ms], dtype=torch.float64)
         dist.all_reduce(sm, op=dist.ReduceOp.MAX)
         kernel_ms = float(sm[0])
@@ -335,7 +462,7 @@ def main():
     if rank == 0:
         config = {
             "workload": args.workload, "rows": rows, "cols": cols, "k": k, "batch": batch,
-            "pairwise": pairwise, "solver": "edge_bethe" if edge else "chain_minsum", "penalty": 0.5, "rho": 1.0,
+            "pairwise": pairwise, "solver": "edge_bethe" if edge else "chain_minsum", "penalty": args.penalty, "rho": 1.0,
             "partition": ("edge slices x%d" % world) if edge else ("row/column strips x%d" % world if batch == 1 else "batch sharded x%d" % world),
             "exchange": args.exchange, "transport": transport,
         }
@@ -379,9 +506,9 @@ def main():
                 "algorithmic_bytes": algo, "algorithmic_gbps": algo / sec / 1e9 if sec > 0 else 0.0,
                 "note": "frac = bytes the kernel moves per launch (HBM counters of a rocprofv3 pass of this command when one is "
                         "committed for this kernel instance, else the stored-representation model) / kernel time / 8 TB/s.  "
-                        "stored_bytes_model is the least this representation can move: theta twice, the multipliers (one "
-                        "int16 array read twice and written once on one device with a Potts table and a power-of-two "
-                        "penalty), byte labels, back-pointer masks.  algorithmic_bytes = V*(32k+16) prices the same launch "
+                        "stored_bytes_model is the least this representation can move: theta twice, the multipliers (on one "
+                        "device one array read twice and written once; int8 or int16 counts with a power-of-two penalty, "
+                        "see config.lam8 / lam16, binary32 otherwise), byte labels, back-pointers.  algorithmic_bytes = V*(32k+16) prices the same launch "
                         "with float32 multipliers, a consensus array and int32 labels; the kernel moves fewer bytes than "
                         "that (same numbers, exact), so algorithmic_gbps may exceed the peak and is not a rate.",
             }
@@ -406,10 +533,21 @@ def main():
             "final_objective": {"primal": float(last[0]), "linear": float(last[1]), "dual": float(last[2])},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(rows, cols, k, pairwise, args.seed, batch)
+        if linear is not None:
+            total = done_its + args.warmup + args.steps
+            out["objective_check"] = objective_check(args.workload, args.penalty, args.seed, done_its + args.warmup + 1,
+                                                     linear, total, last, sha)
     g.FinalizeOptimization()
     g.close()
+    if rank == 0:
+        if world == 1 and args.workload == "2048x2048_k32_potts" and args.penalty == 0.5 and not args.no_secondary:
+            # the same grid where the specialisations of the headline do not apply
+            out["secondary"] = {
+                "general_table": quick_rate("2048x2048_k32_dense", 0.5, args.seed),
+                "binary32_multipliers": quick_rate("2048x2048_k32_potts", 0.3, args.seed),
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(rows, cols, k, pairwise, args.seed, batch)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

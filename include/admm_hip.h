@@ -55,7 +55,10 @@ typedef struct admm_ctx admm_ctx;
 typedef struct admm_desc {
   int32_t rows;          /* numGlobalRows                                     */
   int32_t cols;          /* numGlobalCols                                     */
-  int32_t k;             /* numVertPotentials; chain solver: 2..64            */
+  int32_t k;             /* numVertPotentials, 2..64 for both solvers: a label
+                          * vector is held across the lanes of one wavefront
+                          * (the reference allocates for any k, Tree.cpp:15-22;
+                          * admm_create refuses k > 64 with ADMM_E_ARG)        */
   int32_t batch;         /* independent grids of this shape (>= 1)            */
   int32_t solver;        /* ADMM_SOLVER_*                                     */
   float penalty;         /* admm.cpp:44, first argument                       */
@@ -272,6 +275,10 @@ int admm_edge_log_values(int device, const double *x, double *y, int64_t n);
 
 /* Number of HIP devices visible to this process (0 when there is none). */
 int admm_device_count(void);
+/* Free and total device memory of `device` in bytes as the HIP runtime reports
+ * them (hipMemGetInfo): lets a test see that a call allocated nothing.  A
+ * diagnostic without a counterpart in the reference. */
+int admm_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 
 /* Library version string. */
 const char *admm_version(void);

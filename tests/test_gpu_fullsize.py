@@ -1,5 +1,10 @@
 """The benchmark configurations at full size: the HIP path against the oracle (run with one
-chain per host thread) for a few iterations, plus properties that do not need the oracle."""
+chain per host thread), the headline one for the 25 iterations the benchmark is run with
+(past the first scan of the int8 multiplier counts at sweep 16), plus properties that do
+not need the oracle, plus the committed results of the benchmark's own trajectories
+(tests/golden/bench_objectives.json, written by the oracle in the build container)."""
+import hashlib
+import json
 import os
 
 import numpy as np
@@ -56,7 +61,74 @@ def _run(R, C, k, pw, iters, seed=1234):
 
 
 def test_config_2048x2048_k32_potts():
-    _run(2048, 2048, 32, "potts", 3)
+    _run(2048, 2048, 32, "potts", 25)
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_objectives.json")
+
+
+def _sha(a, dt):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=dt).tobytes()).hexdigest()
+
+
+def _against_golden(name, iters, check_state=True, sync_at=()):
+    """Runs `iters` iterations of a bench workload as bench.py does (queued objectives) and
+    compares with the committed oracle results; returns the grid for further checks."""
+    import admm_amd as A
+    case = json.load(open(GOLDEN))[name]
+    at = case["at"][str(iters)]
+    g = A.Grid()
+    g.SetPartitioner(A.ROW)
+    g.SetPenalties(case["penalty"], 1.0)
+    g.SetGlobalInfo(case["rows"], case["cols"], case["k"], batch=case["batch"])
+    g.Generate(seed=case["seed"], pairwise=case["pairwise"])
+    g.InitOptimization()
+    g._unary = None
+    for it in range(iters):
+        g.Compute(); g.Communicate(); g.Update(); g.ObjectiveEnqueue(1 + it)
+        if it + 1 in sync_at:
+            g.Synchronize()  # (the host looks at scan results that have arrived; it never waits for them)
+    lin = g.ObjectiveRead(1, iters)
+    exp = np.array(case["linear"][:iters])
+    assert np.all(np.abs(lin - exp) <= 1e-9 * np.abs(exp)), "linear objective trace"
+    assert _sha(g.Labels(), "<i4") == at["labels_sha256"], "decoded labels differ from the oracle's"
+    if check_state:
+        assert _sha(g.State(13), "<i4") == at["xrow_sha256"]
+        assert _sha(g.State(14), "<i4") == at["xcol_sha256"]
+        assert _sha(g.State(10), "<f4") == at["lambda_row_sha256"]
+    p, d = g.Objective()
+    assert abs(p - at["primal"]) <= 1e-9 * abs(at["primal"]) and abs(d - at["dual"]) <= 1e-9 * abs(at["dual"])
+    return g
+
+
+def _on_int8(g):
+    return g.SweepKernelName().split(",")[8].strip(" >") == "true"
+
+
+def test_bench_trajectory_55_iterations_headline():
+    """The default benchmark run (5 + 50 iterations): three scans of the int8 counts."""
+    g = _against_golden("2048x2048_k32_potts", 55)
+    assert _on_int8(g)  # the counts of this problem stay small: still int8 at the end
+    g.close()
+
+
+def test_bench_trajectory_int8_counts_widen_in_mid_run_at_full_size(monkeypatch):
+    """A scan threshold of 1 makes the first scan that sees a non-zero count (the one after
+    sweep 5) turn the arrays into int16 while the run goes on; the results must not notice.
+    (The counts of this problem stay within +-1 for these 25 iterations.)"""
+    monkeypatch.setenv("ADMM_LAM8_THR", "1")
+    monkeypatch.setenv("ADMM_LAM8_EVERY", "5")
+    g = _against_golden("2048x2048_k32_potts", 25, sync_at=(12,))
+    assert not _on_int8(g), "the counts were expected to have become int16 by now"
+    g.close()
+
+
+@pytest.mark.parametrize("name", ["2048x2048_k32_dense", "2048x2048_k32_potts_penalty0.3", "1024x1024_k64_dense",
+                                  "512x512_k16_trunc_linear", "256x(256x256)_k8_potts", "64x64_k4_potts"])
+def test_bench_trajectory_25_iterations(name):
+    """The other bench workloads (general table and binary32 multipliers on the headline
+    grid among them) for the 25 iterations the benchmark is run with."""
+    _against_golden(name, 25, check_state=not name.startswith("256x")).close()
 
 
 def test_config_1024x1024_k64_dense():

@@ -36,6 +36,32 @@ def test_static_staging_matches_context_staging_twice_second_smaller():
     big.close(); small.close()
 
 
+def _free_bytes():
+    from admm_amd._lib import lib
+    f, t = C.c_uint64(), C.c_uint64()
+    assert lib.admm_device_memory(0, C.byref(f), C.byref(t)) == 0
+    return f.value
+
+
+def test_static_call_allocates_no_device_memory():
+    """Free device memory as the runtime reports it is the same before and after the static
+    call on a context that has never staged anything; the allocating call on the same
+    context then takes its staging (16 MiB for these 2048 x 2048 labels) and keeps it."""
+    g = _grid(2048, 2048, 2, 3)
+    g.Synchronize()
+    before = _free_bytes()
+    got = g.LabelsStatic()
+    after = _free_bytes()
+    assert after == before, (before, after)
+    want = g.Labels()  # first staging of this context
+    assert _free_bytes() <= before - (16 << 20) + (2 << 20), "the allocating call was expected to take 16 MiB of staging"
+    assert np.array_equal(got, want)
+    mid = _free_bytes()
+    g.LabelsStatic()
+    assert _free_bytes() == mid
+    g.close()
+
+
 def test_static_staging_refuses_what_does_not_fit():
     import admm_amd as A
     from admm_amd._lib import STATIC_LABELS_MAX, lib
