@@ -28,7 +28,7 @@ EXPORTS = [
     "admm_state_size", "admm_partition", "admm_strip_info", "admm_edge_local_info", "admm_edge_local_vertices", "admm_edge_plan",
     "admm_comm_get_unique_id",
     "admm_comm_init", "admm_lcg_fill", "admm_grid_edges", "admm_profile_reset",
-    "admm_profile_read", "admm_sweep_kernel_info", "admm_sweep_kernel_name", "admm_device_count", "admm_device_memory", "admm_version",
+    "admm_profile_read", "admm_sweep_kernel_info", "admm_sweep_kernel_name", "admm_launch_info", "admm_device_count", "admm_device_memory", "admm_version",
     "admm_edge_log_values",
 ]
 
@@ -99,6 +99,7 @@ def _load():
         "admm_profile_read": (C.c_int, [vp, dp, C.POINTER(C.c_int)]),
         "admm_sweep_kernel_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "admm_sweep_kernel_name": (C.c_int, [vp, C.c_char_p, C.c_int]),
+        "admm_launch_info": (C.c_int, [vp, C.c_char_p, C.c_int]),
         "admm_device_count": (C.c_int, []),
         "admm_device_memory": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "admm_edge_log_values": (C.c_int, [C.c_int, dp, dp, C.c_int64]),

@@ -201,6 +201,9 @@ struct admm_ctx {
   ncclComm_t comm = nullptr;
   hipEvent_t ev_packed = nullptr, ev_pulled = nullptr;  // admm_communicate_group
 
+  // the options the last Compute launch ran with (admm_launch_info)
+  std::string launch_info;
+
   // ---- profiling ----
   bool prof = false;
   int prof_every = 1, prof_seen = 0;  // every prof_every-th Compute is timed
@@ -481,6 +484,8 @@ bool direct_labels_chosen(const admm_ctx *c) {
   return !(potts && sh.KP >= 32 && waves >= 4096);
 }
 
+bool red_deferred(const admm_ctx *c);
+
 template <bool DUAL>
 int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
   const bool potts = !DUAL && potts_chosen(c, sh);
@@ -514,6 +519,24 @@ int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
   // grid loses by it (2048 x 2048, k = 32: 0.350 -> 0.362 ms).  ADMM_SWEEP_XCD=0/1 overrides.
   a.xcd_remap = c->d.batch >= 8;
   if (const char *ex = getenv("ADMM_SWEEP_XCD")) a.xcd_remap = atoi(ex) != 0;
+  // Column chains that share a wavefront read adjacent nodes: CPW * k entries of the
+  // multipliers per step.  Below a 128-byte line (int8 counts of 2 x 32 labels) the rest of the
+  // line is the next wavefront pair's; those two pairs then run on one die (see ChainArgs).
+  // ADMM_SWEEP_PAIRXCD=0/1 (tuning and test knob) overrides.
+  {
+    const int entry = c->lam16 ? (c->lam8 ? 1 : 2) : 4;
+    a.pair_xcd = !DUAL && a.mix_blocks > 0 && !a.xcd_remap && CPW * c->d.k * entry < 128;
+    if (const char *ep = getenv("ADMM_SWEEP_PAIRXCD")) a.pair_xcd = atoi(ep) != 0 && a.mix_blocks > 0;
+  }
+  if (!DUAL) {
+    const bool two = (potts && twowave_chosen(sh.KP, w)) || (trunc && twowave_chosen(sh.KP, w, true));
+    char info[256];
+    snprintf(info, sizeof(info), "wavefronts=%d mixed_workgroups=%d pair_xcd=%d xcd_remap=%d two_wavefronts_per_half_chain=%d "
+             "direct_labels=%d deferred_sums=%d multipliers=%s",
+             w, (a.mix_blocks > 0 && !two) ? 1 : 0, (a.pair_xcd && !two) ? 1 : 0, a.xcd_remap, two ? 1 : 0, c->direct_labels ? 1 : 0,
+             red_deferred(c) ? 1 : 0, c->lam16 ? (c->lam8 ? "int8" : "int16") : "binary32");
+    c->launch_info = info;
+  }
   // queued sums ride along as one more workgroup, behind the sweep's own
   const int w_split = w / 2 + (a.red_jobs > 0 ? 1 : 0);
   a.red_block = blocks;
@@ -1136,6 +1159,7 @@ int edge_compute(admm_ctx *c) {
   }
   HIP_TRY(c, hipGetLastError());
   c->edge_obj_n = c->d_edge_obj ? edge_blocks(c->E, c->KP) : 0;
+  c->launch_info = c->d_edge_obj ? "objective_summed_by_the_solve=1" : "objective_summed_by_the_solve=0";
   return ADMM_OK;
 }
 
@@ -2777,6 +2801,14 @@ int admm_sweep_kernel_name(admm_ctx *c, char *buf, int len) {
   else
     snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, %d, %d, %d, false, false, %s, false, %s, false, 0>", sh.KP, sh.NS, sweep_gpb(sh.KP, sh.NS), sweep_minw(sh.KP, sh.NS),
              c->lam16 ? "true" : "false", (c->lam16 && c->lam8) ? "true" : "false");
+  return ADMM_OK;
+}
+
+int admm_launch_info(admm_ctx *c, char *buf, int len) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!buf || len < 1) return fail(c, ADMM_E_ARG, "null buffer");
+  snprintf(buf, (size_t)len, "%s", c->launch_info.c_str());
   return ADMM_OK;
 }
 

@@ -104,6 +104,13 @@ struct ChainArgs {
   // range of each set's chains (chains that lie side by side read the same cache lines of the
   // crossing chains' labels, and every die has a cache of its own).
   int xcd_remap;
+  // Mixed workgroups only.  The memory system moves whole 128-byte lines; where the chains of
+  // one wavefront of seg[1] use less than a line of an operand per step (two adjacent column
+  // chains of 32 int8 counts: 64 bytes), the other part of the line belongs to the next
+  // wavefront pair of the set.  pair_xcd: the pairs 2j and 2j + 1 of seg[1] go to workgroups
+  // eight apart, i.e. to the same die a moment apart, so that the second one finds the line
+  // in that die's cache instead of fetching it from memory again.
+  int pair_xcd;
 };
 
 constexpr int kChainBlock = 256;  // two pairs of wavefronts per workgroup (a pair = the two halves of the same chains)
@@ -418,7 +425,13 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     int wl;
     if (blk < args.mix_blocks) {
       si = wib >> 1;
-      wl = 2 * blk + (wib & 1);
+      int p = blk;
+      if (si == 1 && args.pair_xcd && blk < (args.mix_blocks & ~15)) {
+        // workgroup 8q + x (die x): pair 16 (q / 2) + 2x + q % 2, a bijection of every 16 workgroups
+        const int q = blk >> 3, x = blk & 7;
+        p = ((q >> 1) << 4) + 2 * x + (q & 1);
+      }
+      wl = 2 * p + (wib & 1);
     } else {
       si = args.mix_big;
       wl = 2 * args.mix_blocks + (blk - args.mix_blocks) * WPB + wib;

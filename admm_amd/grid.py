@@ -409,6 +409,16 @@ class Grid:
         self._ck(lib.admm_sweep_kernel_name(self._h, buf, 160))
         return buf.value.decode()
 
+    def LaunchInfo(self):
+        """The options the last Compute launch ran with: {name: value}."""
+        buf = C.create_string_buffer(512)
+        self._ck(lib.admm_launch_info(self._h, buf, 512))
+        out = {}
+        for item in buf.value.decode().split():
+            n, _, v = item.partition("=")
+            out[n] = int(v) if v.lstrip("-").isdigit() else v
+        return out
+
     def close(self):
         if self._h:
             lib.admm_destroy(self._h)

@@ -86,19 +86,28 @@ def sweep_bytes(V, k):
     return V * (32 * k + 16)
 
 
-def stored_bytes(V, k, kp, chains_per_wave, potts, lam_el, lam_shared):
+def stored_bytes(V, k, kp, chains_per_wave, potts, lam_el, lam_shared, pcomp=False, pair_xcd=True):
     """Bytes one sweep launch has to move given how the operands are stored: a lower bound
-    for this representation (every array touched once per use, nothing re-read).
+    for this representation (every line touched once per use, nothing re-read).
       theta       4k per node, read by the row chains and by the column chains
       multipliers one array on one device (read by both sets, written once) or one per set
-                  (each read and written); lam_el bytes per entry: 4 as binary32, 2 or 1 as counts
+                  (each read and written); lam_el bytes per entry: 4 as binary32, 2 or 1 as counts.
+                  The memory system moves whole 128-byte lines: where the column chains of one
+                  wavefront use less than a line per step (2 x 32 int8 counts = 64 bytes) and the
+                  wavefront that uses the rest runs on another die (pair_xcd off), the column
+                  chains' read costs a full line per wavefront
       labels      1 byte: every set reads its own and the crossing chains', writes its own
       back-pointers  Potts step: two 64-bit lane masks per wavefront step (16 B for
                   chains_per_wave nodes), written by the forward pass and read by the
-                  trace-back; general step: one byte per padded label per node, likewise"""
-    lam = lam_el * k * (3 if lam_shared else 4)
+                  trace-back, plus with path compression one byte per lane and block of eight
+                  steps, likewise; general step: one byte per padded label per node, likewise"""
+    piece = chains_per_wave * kp * lam_el
+    col_read = lam_el * k * (1.0 if (piece >= 128 or pair_xcd) else 128.0 / piece)
+    lam = (lam_el * k * 2 if lam_shared else lam_el * k * 3) + col_read
     labels = 2 * 3
     bp = 2 * 2 * (16.0 / chains_per_wave if potts else kp)
+    if potts and pcomp:
+        bp += 2 * 2 * (64.0 / 8 / chains_per_wave)
     return V * (8 * k + lam + labels + bp)
 
 
@@ -190,7 +199,7 @@ def cpu_baseline(rows, cols, k, pairwise, seed, batch=1):
     return out
 
 
-def measured_traffic(workload, world, kernel):
+def measured_traffic(workload, world, kernel, launch=None):
     """HBM bytes per launch of the dominant kernel from the committed counter passes
     (FETCH_SIZE and WRITE_SIZE come from rocprofv3 --pmc runs of this same command; they
     cannot be collected from inside this process).  Only a pass of the same workload and
@@ -205,6 +214,8 @@ def measured_traffic(workload, world, kernel):
         except (OSError, ValueError):
             continue
         if str(d.get("workload", "")).startswith(workload) and kernel in str(d.get("kernel", "")):
+            if launch is not None and d.get("launch") is not None and d.get("launch") != launch:
+                continue  # a pass of the same kernel under other launch options moves other bytes
             return d.get("hbm_bytes_per_launch"), "profiles/" + os.path.basename(f)
     return None, None
 
@@ -470,6 +481,7 @@ def main():
             b_it = edge_bytes(V, E, k)
             kernel = "edge_solve_kernel<%d>" % (1 << max(1, (k - 1).bit_length()))
             config["kernel"] = kernel
+            config["launch"] = g.LaunchInfo()
             traffic, traffic_src = measured_traffic(args.workload, world, "edge_solve_kernel")
             # what the kernel is really bound by: binary64 exp / log on the vector ALU
             transc = E * (4 * k * k + 4 * k)
@@ -489,11 +501,14 @@ def main():
             kernel = g.SweepKernelName()
             flags = [f.strip(" >") for f in kernel.split(",")]
             lam16, lam8 = flags[6] == "true", len(flags) > 8 and flags[8] == "true"
-            config.update({"kernel": kernel, "potts_step": potts, "lam16": lam16, "lam8": lam8})
+            pcomp = len(flags) > 7 and flags[7] == "true"
+            launch = g.LaunchInfo()
+            config.update({"kernel": kernel, "potts_step": potts, "lam16": lam16, "lam8": lam8, "launch": launch})
             b_it = bytes_per_iteration(V, k)
             algo = sweep_bytes(V, k) / world
-            model = stored_bytes(V, k, kp, 64 // (kp * ns), potts, 1 if lam8 else (2 if lam16 else 4), lam_shared=(nprocs_for_grid == 1)) / world
-            traffic, traffic_src = measured_traffic(args.workload, world, kernel)
+            model = stored_bytes(V, k, kp, 64 // (kp * ns), potts, 1 if lam8 else (2 if lam16 else 4), lam_shared=(nprocs_for_grid == 1),
+                                 pcomp=pcomp, pair_xcd=bool(launch.get("pair_xcd", 0)) or bool(launch.get("xcd_remap", 0))) / world
+            traffic, traffic_src = measured_traffic(args.workload, world, kernel, launch)
             moved = traffic if traffic else model
             roof = {
                 "kernel": kernel, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",

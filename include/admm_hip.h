@@ -268,6 +268,15 @@ int admm_sweep_kernel_info(admm_ctx *ctx, int *label_lanes, int *lanes_per_label
  * timed.  buf receives at most len bytes, NUL-terminated. */
 int admm_sweep_kernel_name(admm_ctx *ctx, char *buf, int len);
 
+/* The launch options the last admm_compute ran with, as "name=value" pairs
+ * separated by blanks (chain solver: wavefronts, mixed workgroups, pairs of
+ * column wavefronts per die, die remap, wavefronts per half chain, direct
+ * labels, deferred sums, width of the multipliers; edge solver: whether the
+ * solve summed the objective).  Several of them follow tuning knobs in the
+ * environment, so a measurement records them.  Empty before the first
+ * admm_compute.  A diagnostic without a counterpart in the reference. */
+int admm_launch_info(admm_ctx *ctx, char *buf, int len);
+
 /* The binary64 logarithm the edge solver takes of every marginal
  * (Tree.cpp:120-133), applied on the device to n host values: y[i] = log x[i].
  * For accuracy tests of that function; no counterpart in the reference. */

@@ -7,8 +7,11 @@ launch.
     python tools/distill_profiles.py r02
 
 HBM bytes: FETCH_SIZE and WRITE_SIZE are reported in KiB.  On gfx950
-FETCH_SIZE counts 64 B for each 128-B read request, so reads are doubled; the
-factor is checked in the same pass on a kernel whose read volume is known
+FETCH_SIZE counts 64 B for each 128-B read request, so reads are doubled.  The
+factor holds for every access width the sweep uses (the L2 fetches whole
+128-byte lines whatever part of a line a wavefront asks for:
+tools/fetch_calibration.hip, profiles/r03_fetch_calibration.json), and it is
+checked again in the same pass on a kernel whose read volume is known
 (chain_init_theta_kernel reads its array exactly once).  WRITE_SIZE needs no
 correction.
 """
@@ -73,7 +76,7 @@ def main():
         out = {
             "command": "rocprofv3 --pmc FETCH_SIZE -- python bench.py --workload '%s' --steps 3 --warmup 1 --no-cpu-baseline ; "
                        "the same with --pmc WRITE_SIZE (separate passes)" % cfg["workload"],
-            "kernel": fk[0], "workload": cfg["workload"] + ", 1 GPU",
+            "kernel": fk[0], "workload": cfg["workload"] + ", 1 GPU", "launch": cfg.get("launch"),
             "FETCH_SIZE_KiB_per_launch": fetch[fk[0]], "WRITE_SIZE_KiB_per_launch": write[wk[0]],
             "fetch_correction": 2.0, "fetch_correction_check": check,
             "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
