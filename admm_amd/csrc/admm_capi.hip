@@ -62,6 +62,15 @@ struct Strip {
   int row0 = 0, nrows = 0, col0 = 0, ncols = 0;
 };
 
+// Chain solver on several strips.  Offsets (in labels) of the per-peer send blocks inside sendbuf:
+//   a-blocks: my row-chain labels on peer h's columns, nr x nc_h each, then
+//   b-blocks: my column-chain labels on peer h's rows, nc x nr_h each.
+// Host arithmetic on the problem's sizes, worked out once per context.
+struct ExchangePlan {
+  std::vector<long long> off_a, off_b;  // size G + 1
+  std::vector<int> r0, nr, c0, nc;      // every rank's strips
+};
+
 }  // namespace
 
 struct admm_ctx {
@@ -198,8 +207,14 @@ struct admm_ctx {
   void *d_stage = nullptr;
   size_t stage_bytes = 0;
 
+  ExchangePlan plan;
+  bool plan_ready = false;
   ncclComm_t comm = nullptr;
   hipEvent_t ev_packed = nullptr, ev_pulled = nullptr;  // admm_communicate_group
+  // admm_communicate_group pulled the labels straight into the arrays the sweep reads
+  // (pull_labels_kernel): the admm_update that follows has nothing left to transpose
+  bool pulled = false;
+  label_t *xo_r_alt = nullptr, *xo_c_alt = nullptr;  // where a pull writes; admm_update swaps them in
 
   // the options the last Compute launch ran with (admm_launch_info)
   std::string launch_info;
@@ -1398,6 +1413,7 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
     } else {
       if ((rc = dev_alloc(c, &c->th_c, ncol_nodes * k + 2 * slack)) ||
           (rc = dev_alloc(c, &c->xrow_c, ncol_nodes)) || (rc = dev_alloc(c, &c->xcolT_r, nrow_nodes)) ||
+          (rc = dev_alloc(c, &c->xo_r_alt, nrow_nodes)) || (rc = dev_alloc(c, &c->xo_c_alt, ncol_nodes)) ||
           (rc = dev_alloc(c, &c->sendbuf, nrow_nodes + ncol_nodes)))
         return bail(rc);
       if (d.exchange == ADMM_EXCHANGE_DENSE &&
@@ -1689,6 +1705,7 @@ int admm_init(admm_ctx *c) {
     c->xrow_r = c->xrow_pub = c->xrow_buf[0];
     c->xcolT_c = c->xcolT_pub = c->xcolT_buf[0];
     c->xo_stale = false;
+    c->pulled = false;
     c->red_q.clear();
     if (d.nranks == 1) {
       if (nrow > 0) HIP_TRY(c, hipMemsetAsync(c->xrow_buf[1], 0xFF, sizeof(label_t) * nrow, s));
@@ -1818,18 +1835,11 @@ int admm_compute(admm_ctx *c) {
 
 namespace {
 
-// Offsets (in labels) of the per-peer send blocks inside sendbuf:
-//   a-blocks: my row-chain labels on peer h's columns, nr x nc_h each, then
-//   b-blocks: my column-chain labels on peer h's rows, nc x nr_h each.
-struct ExchangePlan {
-  std::vector<long long> off_a, off_b;  // size G + 1
-  std::vector<int> r0, nr, c0, nc;      // every rank's strips
-};
-
-ExchangePlan make_plan(const admm_ctx *c) {
+const ExchangePlan &plan_of(admm_ctx *c) {
+  if (c->plan_ready) return c->plan;
   const admm_desc &d = c->d;
   const int G = d.nranks;
-  ExchangePlan p;
+  ExchangePlan &p = c->plan;
   p.off_a.assign(G + 1, 0); p.off_b.assign(G + 1, 0);
   p.r0.resize(G); p.nr.resize(G); p.c0.resize(G); p.nc.resize(G);
   for (int h = 0; h < G; h++) {
@@ -1840,6 +1850,7 @@ ExchangePlan make_plan(const admm_ctx *c) {
     p.off_a[h + 1] = p.off_a[h] + (long long)c->st.nrows * p.nc[h];
     p.off_b[h + 1] = p.off_b[h] + (long long)c->st.ncols * p.nr[h];
   }
+  c->plan_ready = true;
   return p;
 }
 
@@ -1949,7 +1960,7 @@ int admm_communicate(admm_ctx *c) {
   hipStream_t s = c->stream;
   const int G = d.nranks;
   const int nr = c->st.nrows, nc = c->st.ncols;
-  const ExchangePlan p = make_plan(c);
+  const ExchangePlan &p = plan_of(c);
   const bool own_direct = d.exchange == ADMM_EXCHANGE_LABELS;
   if ((rc = pack_labels(c, p, own_direct))) return rc;
   const Wire w = wire_of(c);
@@ -1996,7 +2007,7 @@ int admm_exchange_counts(admm_ctx *c, int64_t *send_counts, int64_t *recv_counts
     }
     return ADMM_OK;
   }
-  const ExchangePlan p = make_plan(c);
+  const ExchangePlan &p = plan_of(c);
   for (int h = 0; h < c->d.nranks; h++) {
     const int64_t m = c->d.exchange == ADMM_EXCHANGE_DENSE ? c->d.k : 1;
     if (send_counts) send_counts[h] = m * ((int64_t)c->st.nrows * p.nc[h] + (int64_t)c->st.ncols * p.nr[h]);
@@ -2019,7 +2030,7 @@ int admm_exchange_pack_host(admm_ctx *c, int32_t *host_send) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return ADMM_OK;
   }
-  const ExchangePlan p = make_plan(c);
+  const ExchangePlan &p = plan_of(c);
   if ((rc = pack_labels(c, p))) return rc;
   const int G = c->d.nranks;
   const Wire w = wire_of(c);
@@ -2049,7 +2060,7 @@ int admm_exchange_unpack_host(admm_ctx *c, const int32_t *host_recv) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return ADMM_OK;
   }
-  const ExchangePlan p = make_plan(c);
+  const ExchangePlan &p = plan_of(c);
   const int nr = c->st.nrows, nc = c->st.ncols;
   const int32_t *src = host_recv;
   const Wire w = wire_of(c);
@@ -2064,6 +2075,27 @@ int admm_exchange_unpack_host(admm_ctx *c, const int32_t *host_recv) {
   if ((rc = unpack_received(c))) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller's buffer may be reused at once
   return ADMM_OK;
+}
+
+// Can every strip of the group read the others' label arrays from its own kernels?  Label
+// exchange only; all strips on one device, or on devices that grant each other peer access
+// (asked for here, once per pair).  ADMM_GROUP_PULL=0 (tuning and test knob) keeps the
+// pack / copy / transpose form.
+static bool group_pull_ok(admm_ctx **ctxs, int n) {
+  if (n > kPullMaxStrips || !is_chain(ctxs[0]) || ctxs[0]->d.exchange != ADMM_EXCHANGE_LABELS) return false;
+  if (const char *e = getenv("ADMM_GROUP_PULL")) if (atoi(e) == 0) return false;
+  for (int g = 0; g < n; g++)
+    for (int h = 0; h < n; h++) {
+      const int dg = ctxs[g]->d.device, dh = ctxs[h]->d.device;
+      if (dg == dh) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, dg, dh) != hipSuccess || !can) return false;
+      if (hipSetDevice(dg) != hipSuccess) return false;
+      const hipError_t e = hipDeviceEnablePeerAccess(dh, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return false; }
+      if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+    }
+  return true;
 }
 
 int admm_communicate_group(admm_ctx **ctxs, int n) {
@@ -2114,15 +2146,54 @@ int admm_communicate_group(admm_ctx **ctxs, int n) {
     }
     return ADMM_OK;
   }
-  std::vector<ExchangePlan> plans;
   int rc;
+  if (group_pull_ok(ctxs, n)) {
+    // Every strip pulls its labels from the other strips' arrays and lays them out along its
+    // chains in the same launch: no pack, no copies, and nothing left for admm_update.
+    for (int g = 0; g < n; g++) {
+      admm_ctx *c = ctxs[g];
+      if ((rc = check_ctx(c))) return rc;
+      if (!c->ev_packed) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
+      if (!c->ev_pulled) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_pulled, hipEventDisableTiming));
+      HIP_TRY(c, hipEventRecord(c->ev_packed, c->stream));  // my chains' labels are final
+    }
+    for (int h = 0; h < n; h++) {
+      admm_ctx *r = ctxs[h];
+      if ((rc = check_ctx(r))) return rc;
+      for (int g = 0; g < n; g++)
+        if (g != h) HIP_TRY(r, hipStreamWaitEvent(r->stream, ctxs[g]->ev_packed, 0));
+      PullArgs a{};
+      for (int g = 0; g < n; g++) { a.src_row[g] = ctxs[g]->xrow_r; a.src_colT[g] = ctxs[g]->xcolT_c; }
+      a.G = n; a.rows = r->d.rows; a.cols = r->d.cols;
+      a.r0 = r->st.row0; a.nr = r->st.nrows; a.c0 = r->st.col0; a.nc = r->st.ncols;
+      a.recv_a = r->xrow_c; a.recv_b = r->xcolT_r; a.xo_c = r->xo_c_alt; a.xo_r = r->xo_r_alt;
+      a.tiles_a_minor = (a.nc + 63) / 64; a.tiles_b_minor = (a.nr + 63) / 64;
+      a.tiles_a = a.nc > 0 ? ((a.rows + 63) / 64) * a.tiles_a_minor : 0;
+      const int tiles_b = a.nr > 0 ? ((a.cols + 63) / 64) * a.tiles_b_minor : 0;
+      if (a.tiles_a + tiles_b > 0) {
+        hipLaunchKernelGGL(pull_labels_kernel, dim3((unsigned)(a.tiles_a + tiles_b)), dim3(256), 0, r->stream, a);
+        HIP_TRY(r, hipGetLastError());
+      }
+      r->pulled = true;
+      HIP_TRY(r, hipEventRecord(r->ev_pulled, r->stream));
+    }
+    // a strip's next sweep overwrites its labels: not before everybody has pulled them
+    for (int g = 0; g < n; g++) {
+      admm_ctx *c = ctxs[g];
+      if ((rc = check_ctx(c))) return rc;
+      for (int h = 0; h < n; h++)
+        if (h != g) HIP_TRY(c, hipStreamWaitEvent(c->stream, ctxs[h]->ev_pulled, 0));
+    }
+    return ADMM_OK;
+  }
+  std::vector<const ExchangePlan *> plans;
   // 1. every strip packs on its own stream and marks the point
   for (int g = 0; g < n; g++) {
     admm_ctx *c = ctxs[g];
     if ((rc = check_ctx(c))) return rc;
-    plans.push_back(make_plan(c));
+    plans.push_back(&plan_of(c));
     // label mode: a strip's own blocks go straight into its receive arrays (as in admm_communicate)
-    if ((rc = pack_labels(c, plans[g], c->d.exchange == ADMM_EXCHANGE_LABELS))) return rc;
+    if ((rc = pack_labels(c, *plans[g], c->d.exchange == ADMM_EXCHANGE_LABELS))) return rc;
     if (!c->ev_packed) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
     if (!c->ev_pulled) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_pulled, hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(c->ev_packed, c->stream));
@@ -2134,7 +2205,7 @@ int admm_communicate_group(admm_ctx **ctxs, int n) {
     const int nr = r->st.nrows, nc = r->st.ncols;
     for (int g = 0; g < n; g++) {
       admm_ctx *sd = ctxs[g];
-      const ExchangePlan &p = plans[g];
+      const ExchangePlan &p = *plans[g];
       if (g == h && r->d.exchange == ADMM_EXCHANGE_LABELS) continue;  // already in place
       HIP_TRY(r, hipStreamWaitEvent(r->stream, sd->ev_packed, 0));
       const Wire ws = wire_of(sd), wr = wire_of(r);
@@ -2186,6 +2257,12 @@ int admm_update(admm_ctx *c) {
   }
   if (c->one_strip())
     return transpose_labels2<label_t>(c, c->xo_r, c->xcolT_c, d.cols, c->st.nrows, c->xo_c, c->xrow_r, d.rows, c->st.ncols);
+  if (c->pulled) {  // admm_communicate_group laid them out already, in the spare arrays
+    c->pulled = false;
+    std::swap(c->xo_r, c->xo_r_alt);
+    std::swap(c->xo_c, c->xo_c_alt);
+    return ADMM_OK;
+  }
   return transpose_labels2<int>(c, c->xo_r, c->xcolT_r, d.cols, c->st.nrows, c->xo_c, c->xrow_c, d.rows, c->st.ncols);
 }
 

@@ -2480,6 +2480,64 @@ __global__ void pack_strip_labels_kernel(int *__restrict__ send_a, int *__restri
   }
 }
 
+// The strip exchange and Update's transposition in one launch, for strips whose label arrays
+// this device can read directly (all strips of a problem held by one process): strip h PULLS.
+// Job a, for its column chains: the labels of every strip's row chains on h's columns,
+//   v = xrow_g[r - r0_g][c0_h + c]  ->  recv_a[r][c] (int32, as the exchange leaves them) and
+//   xo_c[c][r] (bytes along h's column chains, as Update's transposition leaves them);
+// job b, for its row chains: the labels of every strip's column chains on h's rows,
+//   v = xcolT_g[c - c0_g][r0_h + r]  ->  recv_b[c][r] and xo_r[r][c].
+// 64 x 64 tiles through LDS like transpose_labels_kernel; the workgroups of job b follow
+// those of job a.
+constexpr int kPullMaxStrips = 64;
+struct PullArgs {
+  const label_t *src_row[kPullMaxStrips];   // xrow of strip g: [nr_g][cols]
+  const label_t *src_colT[kPullMaxStrips];  // xcolT of strip g: [nc_g][rows]
+  int G, rows, cols;
+  int r0, nr, c0, nc;                       // the pulling strip
+  int *recv_a;     // [rows][nc]
+  int *recv_b;     // [cols][nr]
+  label_t *xo_c;   // [nc][rows]
+  label_t *xo_r;   // [nr][cols]
+  int tiles_a, tiles_a_minor, tiles_b_minor;  // workgroups of job a; tiles along the minor axis of each job
+};
+
+__global__ __launch_bounds__(256) void pull_labels_kernel(const PullArgs a) {
+  __shared__ label_t s_t[64][64 + 4];
+  const bool jb = (int)blockIdx.x >= a.tiles_a;
+  const int blk = jb ? blockIdx.x - a.tiles_a : blockIdx.x;
+  // job a: major = grid row (all of them), minor = my columns; job b: major = grid column, minor = my rows
+  const int nmaj = jb ? a.cols : a.rows, nmin = jb ? a.nr : a.nc, off_min = jb ? a.r0 : a.c0;
+  const int pitch = jb ? a.rows : a.cols;  // row pitch of a source array
+  const int tiles_minor = jb ? a.tiles_b_minor : a.tiles_a_minor;
+  const int m0 = (blk / tiles_minor) * 64, n0 = (blk % tiles_minor) * 64;
+  int *__restrict__ recv = jb ? a.recv_b : a.recv_a;
+  label_t *__restrict__ xo = jb ? a.xo_r : a.xo_c;
+  label_t v[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const int i = threadIdx.x + 256 * j;
+    const int mj = min(m0 + (i >> 6), nmaj - 1), mn = min(n0 + (i & 63), nmin - 1);
+    int st, cnt;
+    const int g = owner_of(mj, nmaj, a.G, &st, &cnt);
+    const label_t *__restrict__ src = jb ? a.src_colT[g] : a.src_row[g];
+    v[j] = src[(long long)(mj - st) * pitch + off_min + mn];
+  }
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const int i = threadIdx.x + 256 * j;
+    s_t[i >> 6][i & 63] = v[j];
+    if (m0 + (i >> 6) < nmaj && n0 + (i & 63) < nmin) recv[(long long)(m0 + (i >> 6)) * nmin + n0 + (i & 63)] = (int)v[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const int i = threadIdx.x + 256 * j;
+    const int hi = i >> 6, lo = i & 63;
+    if (n0 + hi < nmin && m0 + lo < nmaj) xo[(long long)(n0 + hi) * nmaj + m0 + lo] = s_t[lo][hi];
+  }
+}
+
 // Dense form of the strip exchange: the marginals of the chains' own
 // solutions as float k-vectors (one-hot of the label; 1/k everywhere before
 // the first solve), which is what the reference moves between ranks
