@@ -1145,7 +1145,8 @@ void build_incidence(admm_ctx *c) {
 }
 
 int edge_blocks(int E, int KP) {
-  const int gpb = (kEdgeBlock / 64) * (64 / KP);
+  // up to 64 labels: 64 / KP edges per wavefront; beyond: one edge per wavefront (edge_solve_big_kernel)
+  const int gpb = KP <= 64 ? (kEdgeBlock / 64) * (64 / KP) : edge_big_epb(KP);
   return (E + gpb - 1) / gpb;
 }
 
@@ -1170,7 +1171,12 @@ int edge_compute(admm_ctx *c) {
     case 16: launch_edge_t<16>(a, c->stream); break;
     case 32: launch_edge_t<32>(a, c->stream); break;
     case 64: launch_edge_t<64>(a, c->stream); break;
-    default: return fail(c, ADMM_E_ARG, "edge solver supports k <= 64 (k=%d)", c->d.k);
+    // more labels than lanes: the table of an edge stays in HBM
+    case 128: hipLaunchKernelGGL((edge_solve_big_kernel<128>), dim3(edge_blocks(a.E, 128)), dim3(64 * edge_big_epb(128)), 0, c->stream, a); break;
+    case 256: hipLaunchKernelGGL((edge_solve_big_kernel<256>), dim3(edge_blocks(a.E, 256)), dim3(64 * edge_big_epb(256)), 0, c->stream, a); break;
+    case 512: hipLaunchKernelGGL((edge_solve_big_kernel<512>), dim3(edge_blocks(a.E, 512)), dim3(64 * edge_big_epb(512)), 0, c->stream, a); break;
+    case 1024: hipLaunchKernelGGL((edge_solve_big_kernel<1024>), dim3(edge_blocks(a.E, 1024)), dim3(64 * edge_big_epb(1024)), 0, c->stream, a); break;
+    default: return fail(c, ADMM_E_ARG, "edge solver supports k <= %d (k=%d)", kEdgeBigMaxK, c->d.k);
   }
   HIP_TRY(c, hipGetLastError());
   c->edge_obj_n = c->d_edge_obj ? edge_blocks(c->E, c->KP) : 0;
@@ -1254,7 +1260,9 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
   *out = nullptr;
   const admm_desc &d = *desc;
   if (d.k < 2) return fail(nullptr, ADMM_E_ARG, "k must be >= 2 (k=%d)", d.k);
-  if (d.k > 64) return fail(nullptr, ADMM_E_ARG, "k must be <= 64 (k=%d)", d.k);
+  if (d.solver == ADMM_SOLVER_CHAIN_MINSUM && d.k > 64)
+    return fail(nullptr, ADMM_E_ARG, "the chain solver holds a label vector across the lanes of one wavefront: k must be <= 64 (k=%d)", d.k);
+  if (d.k > kEdgeBigMaxK) return fail(nullptr, ADMM_E_ARG, "k must be <= %d (k=%d)", kEdgeBigMaxK, d.k);
   if (d.batch < 1) return fail(nullptr, ADMM_E_ARG, "batch must be >= 1");
   if (d.nranks < 1 || d.rank < 0 || d.rank >= d.nranks) return fail(nullptr, ADMM_E_ARG, "bad rank %d of %d", d.rank, d.nranks);
   if (!(d.penalty > 0.f) || !(d.rho > 0.f)) return fail(nullptr, ADMM_E_ARG, "penalty and rho must be positive");
@@ -1356,7 +1364,7 @@ int admm_create(const admm_desc *desc, admm_ctx **out) {
     // separate pass over the marginals
     const char *fo = getenv("ADMM_EDGE_FUSED_OBJ");
     c->edge_obj_n = 0;
-    if (c->KP <= 64 && !(fo && atoi(fo) == 0) &&
+    if (!(fo && atoi(fo) == 0) &&
         (rc = dev_alloc(c, &c->d_edge_obj, (size_t)edge_blocks(c->E, c->KP))))
       return bail(rc);
     hipError_t e1 = h2d_sync(c, c->d_edges, c->h_edges.data(), sizeof(int) * 2 * E);

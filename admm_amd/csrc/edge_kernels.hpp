@@ -280,6 +280,201 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
   }
 }
 
+// Tree.cpp:64-274 for more labels than a wavefront has lanes (64 < k <= KMAX): one edge per
+// wavefront, lane l owns the labels l, l + 64, ...; the k x k table of adjusted potentials
+// and, after it, of exponentials lives in HBM, in place of the edge marginal it is worked
+// out from and becomes (every entry is read before it is overwritten), the node vectors
+// in LDS.  Every sum runs in the reference's order and in the reference's precision, with
+// the arithmetic of edge_solve_kernel's general form (which equals its specialised forms
+// bit for bit), so the two kernels agree wherever both apply.  The reference allocates for
+// any k (Tree.cpp:15-22); this is the path that keeps that open, not a fast one: the
+// row walks are strided across lanes.
+constexpr int kEdgeBigMaxK = 1024;
+// edges (= wavefronts) per workgroup: what the node vectors of KMAX labels leave room for in LDS
+constexpr int edge_big_epb(int KMAX) { return KMAX <= 256 ? 4 : 1; }
+template <int KMAX>
+__global__ __launch_bounds__(64 * edge_big_epb(KMAX)) void edge_solve_big_kernel(const EdgeArgs p) {
+  constexpr int EPB = edge_big_epb(KMAX);
+  __shared__ float s_np[EPB][2 * KMAX];   // node potentials of both endpoints
+  __shared__ float s_lmu[EPB][2 * KMAX];  // log mu of both endpoints
+  __shared__ float s_buf[EPB][KMAX];
+  __shared__ float s_m12[EPB][KMAX], s_m21[EPB][KMAX], s_mu1[EPB][KMAX], s_rs[EPB][KMAX];
+  __shared__ LogPiece s_log[kLogPieces];
+  __shared__ double s_obj[EPB];
+  for (int t = threadIdx.x; t < 2 * kLogPieces; t += 64 * EPB)
+    reinterpret_cast<double *>(s_log)[t] = reinterpret_cast<const double *>(d_log_table)[t];
+  __syncthreads();
+
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long e = (long long)blockIdx.x * EPB + wv;
+  const int k = p.k;
+  const long long k2 = (long long)k * k;
+  const float EPS = 0.00000000000000001;  // Tree.h:15
+  const float pen = p.penalty, pp = p.penaltyPrime, rho = p.rho;
+  const float inv_pp = 1.0f / pp;
+  const double rpp = 1.0 / (double)pp;
+  const bool pp_pow2 = (__float_as_uint(pp) & 0x807fffffu) == 0 && (__float_as_uint(pp) >> 23) != 0 &&
+                       (__float_as_uint(pp) >> 23) != 255 && (__float_as_uint(inv_pp) & 0x7f800000u) != 0 &&
+                       inv_pp * pp == 1.0f;
+  float *np = s_np[wv], *lmu = s_lmu[wv], *buf = s_buf[wv];
+  double oacc = 0.0;
+  if (e < p.E) {
+    float *__restrict__ tab = p.mu_edge + e * k2;          // x_mu_edge, then the scratch, then x_mu_edge again
+    const float *__restrict__ pe_tab = p.pot_edge + e * k2;
+    // node vectors (Tree.cpp:64-73, 84-86, 48-51, 120-122, 141-143, 157-160)
+    for (int h = 0; h < 2; h++) {
+      const int v = p.edgeList[2 * e + h];
+      for (int i = lane; i < k; i += 64) {
+        const float mu = p.mu_node[e * 2 * k + h * k + i], m = p.m_vert[(long long)v * k + i];
+        float lam = p.lam_node[e * 2 * k + h * k + i];
+        const float pot = p.pot_node[e * 2 * k + h * k + i];
+        lam = lam + pen * (mu - m);
+        p.lam_node[e * 2 * k + h * k + i] = lam;
+        const float xnode = rho * (pot + lam) - pen * (m - mu);
+        const float muc = ((double)mu <= 0.0) ? EPS : mu;
+        const float lv = (float)edge_log((double)muc, s_log);
+        const float nd = (float)(-1.0 - (double)lv);
+        float val = xnode + pp * nd;
+        val = pp_pow2 ? val * inv_pp : val / pp;
+        np[h * KMAX + i] = 0.0f - val;
+        lmu[h * KMAX + i] = lv;
+      }
+    }
+    edge_lds_fence();
+    // edge derivatives and potentials, message 1 -> 2 (Tree.cpp:123-133, 144-150, 98-99, 169-172,
+    // 191-205): lane b walks column b
+    constexpr int kAhead = 8;
+    for (int b = lane; b < k; b += 64) {
+      const float lmu2 = lmu[KMAX + b];
+      float acc = 0.0f;
+      for (int a0 = 0; a0 < k; a0 += kAhead) {
+        float mue_b[kAhead], pe_b[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; u++) {
+          const int a = min(a0 + u, k - 1);
+          mue_b[u] = tab[(long long)a * k + b];
+          pe_b[u] = pe_tab[(long long)a * k + b];
+        }
+#pragma unroll
+        for (int u = 0; u < kAhead; u++) {
+          const int a = a0 + u;
+          if (a < k) {
+            const float mue = mue_b[u];
+            const float muec = ((double)mue <= 0.0) ? EPS : mue;
+            float ed = (float)(((double)lmu[a] - edge_log((double)muec, s_log)) + 1.0);
+            ed = ed + lmu2;
+            const float xe = rho * pe_b[u];
+            float val = xe + pp * ed;
+            val = pp_pow2 ? val * inv_pp : edge_divide(val, (double)pp, rpp);
+            const float epv = 0.0f - val;
+            tab[(long long)a * k + b] = epv;
+            const float c = epv + np[a];
+            acc = (float)((double)acc + exp((double)c));
+          }
+        }
+      }
+      buf[b] = acc;
+    }
+    // the row walks below read what other lanes of this wavefront wrote to memory
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    edge_lds_fence();
+    float sum = 0.0f;
+    for (int j = 0; j < k; j++) sum += buf[j];
+    for (int b = lane; b < k; b += 64) s_m12[wv][b] = buf[b] / sum;
+    edge_lds_fence();
+    // message 2 -> 1 and the exponentials of the edge marginal (Tree.cpp:212-229, 256-268): lane a walks row a
+    for (int a = lane; a < k; a += 64) {
+      const float np_own = np[a];
+      float acc = 0.0f, row_sum = 0.0f;
+      for (int b0 = 0; b0 < k; b0 += kAhead) {
+        float ep_b[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; u++) ep_b[u] = tab[(long long)a * k + min(b0 + u, k - 1)];
+#pragma unroll
+        for (int u = 0; u < kAhead; u++) {
+          const int b = b0 + u;
+          if (b < k) {
+            const float epv = ep_b[u], n2 = np[KMAX + b];
+            const float c = epv + n2;
+            acc = (float)((double)acc + exp((double)c));
+            float q = epv + np_own;
+            q = q + n2;
+            const float ex = (float)exp((double)q);
+            tab[(long long)a * k + b] = ex;
+            row_sum = row_sum + ex;
+          }
+        }
+      }
+      buf[a] = acc;
+      s_rs[wv][a] = row_sum;
+    }
+    edge_lds_fence();
+    sum = 0.0f;
+    for (int j = 0; j < k; j++) sum += buf[j];
+    for (int a = lane; a < k; a += 64) s_m21[wv][a] = buf[a] / sum;
+    edge_lds_fence();
+    // node marginals (Tree.cpp:236-254)
+    for (int a = lane; a < k; a += 64) buf[a] = (float)(exp((double)np[a]) * (double)s_m21[wv][a]);
+    edge_lds_fence();
+    sum = 0.0f;
+    for (int j = 0; j < k; j++) sum += buf[j];
+    for (int a = lane; a < k; a += 64) {
+      const float mu1 = buf[a] / sum;
+      s_mu1[wv][a] = mu1;
+      p.mu_node[e * 2 * k + a] = mu1;
+      const float pr = p.pot_node[e * 2 * k + a] * mu1;
+      oacc += (double)pr;
+    }
+    edge_lds_fence();
+    for (int b = lane; b < k; b += 64) buf[b] = (float)(exp((double)np[KMAX + b]) * (double)s_m12[wv][b]);
+    edge_lds_fence();
+    sum = 0.0f;
+    for (int j = 0; j < k; j++) sum += buf[j];
+    for (int b = lane; b < k; b += 64) {
+      const float mu2 = buf[b] / sum;
+      p.mu_node[e * 2 * k + k + b] = mu2;
+      const float pr = p.pot_node[e * 2 * k + k + b] * mu2;
+      oacc += (double)pr;
+    }
+    // edge marginal (Tree.cpp:269-273) and its share of the linear objective (Grid.cpp:1665-1680)
+    for (int a = lane; a < k; a += 64) {
+      const float row_sum = s_rs[wv][a], mu1 = s_mu1[wv][a];
+      const double accd = (double)row_sum, racc = 1.0 / accd;
+      const bool acc_nz = row_sum != 0.0f;
+      for (int b0 = 0; b0 < k; b0 += kAhead) {
+        float ex_b[kAhead], pe_b[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; u++) {
+          const int b = min(b0 + u, k - 1);
+          ex_b[u] = tab[(long long)a * k + b];
+          pe_b[u] = pe_tab[(long long)a * k + b];
+        }
+#pragma unroll
+        for (int u = 0; u < kAhead; u++) {
+          const int b = b0 + u;
+          if (b < k) {
+            const float q = edge_divide(mu1 * ex_b[u], accd, racc);
+            const float m = acc_nz ? q : 0.0f;
+            tab[(long long)a * k + b] = m;
+            const float pr = pe_b[u] * m;
+            oacc += (double)pr;
+          }
+        }
+      }
+    }
+  }
+  if (p.obj_part == nullptr) return;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) oacc += __shfl_xor(oacc, d);
+  if (lane == 0) s_obj[wv] = oacc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = s_obj[0];
+    for (int w = 1; w < EPB; w++) t += s_obj[w];
+    p.obj_part[blockIdx.x] = t;
+  }
+}
+
 // Sum of the solve's per-workgroup objective terms: one workgroup, one value.
 __global__ __launch_bounds__(1024) void edge_objective_sum_kernel(double *__restrict__ dst,
                                                                    const double *__restrict__ part, int n) {

@@ -55,10 +55,12 @@ typedef struct admm_ctx admm_ctx;
 typedef struct admm_desc {
   int32_t rows;          /* numGlobalRows                                     */
   int32_t cols;          /* numGlobalCols                                     */
-  int32_t k;             /* numVertPotentials, 2..64 for both solvers: a label
-                          * vector is held across the lanes of one wavefront
-                          * (the reference allocates for any k, Tree.cpp:15-22;
-                          * admm_create refuses k > 64 with ADMM_E_ARG)        */
+  int32_t k;             /* numVertPotentials.  Edge solver: 2..1024 (the
+                          * reference allocates for any k, Tree.cpp:15-22;
+                          * beyond 64 labels an edge's table stays in HBM).
+                          * Chain solver: 2..64, a label vector is held across
+                          * the lanes of one wavefront.  admm_create refuses
+                          * anything else with ADMM_E_ARG                     */
   int32_t batch;         /* independent grids of this shape (>= 1)            */
   int32_t solver;        /* ADMM_SOLVER_*                                     */
   float penalty;         /* admm.cpp:44, first argument                       */

@@ -76,8 +76,13 @@ def test_create_rejects_bad_arguments_and_reports_why():
     d.penalty, d.penalty_prime, d.rho, d.nranks = 0.5, 1.0, 1.0, 1
     assert lib.admm_create(C.byref(d), C.byref(h)) == -1
     assert b"k must be" in lib.admm_last_error(None)
-    d.k = 65
+    d.k = 65  # the chain solver holds a label vector across one wavefront's lanes
     assert lib.admm_create(C.byref(d), C.byref(h)) == -1
+    assert b"k must be <= 64" in lib.admm_last_error(None)
+    d.k, d.solver = 1025, 0  # the edge solver goes on to 1024 labels
+    assert lib.admm_create(C.byref(d), C.byref(h)) == -1
+    assert b"k must be <= 1024" in lib.admm_last_error(None)
+    d.solver = 1
     d.k, d.solver = 4, 7
     assert lib.admm_create(C.byref(d), C.byref(h)) == -1
     assert b"solver" in lib.admm_last_error(None)
