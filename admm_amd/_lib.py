@@ -29,7 +29,7 @@ EXPORTS = [
     "admm_comm_get_unique_id",
     "admm_comm_init", "admm_lcg_fill", "admm_grid_edges", "admm_profile_reset",
     "admm_profile_read", "admm_sweep_kernel_info", "admm_sweep_kernel_name", "admm_launch_info", "admm_device_count", "admm_device_memory", "admm_version",
-    "admm_edge_log_values",
+    "admm_edge_log_values", "admm_edge_exp_values",
 ]
 
 
@@ -103,6 +103,7 @@ def _load():
         "admm_device_count": (C.c_int, []),
         "admm_device_memory": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "admm_edge_log_values": (C.c_int, [C.c_int, dp, dp, C.c_int64]),
+        "admm_edge_exp_values": (C.c_int, [C.c_int, fp, dp, dp, C.POINTER(C.c_ubyte), C.c_int64]),
         "admm_version": (C.c_char_p, []),
     }
     for name, (res, args) in sig.items():

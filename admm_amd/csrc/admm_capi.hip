@@ -1225,6 +1225,27 @@ int admm_edge_log_values(int device, const double *x, double *y, int64_t n) {
   return rc;
 }
 
+int admm_edge_exp_values(int device, const float *x, double *own, double *lib, unsigned char *was_nan, int64_t n) {
+  if (!x || !own || !lib || !was_nan || n < 0) return fail(nullptr, ADMM_E_ARG, "bad argument");
+  if (n == 0) return ADMM_OK;
+  if (hipSetDevice(device) != hipSuccess) return fail(nullptr, ADMM_E_HIP, "hipSetDevice(%d) failed", device);
+  float *dx = nullptr;
+  double *d1 = nullptr, *d2 = nullptr;
+  unsigned char *dn = nullptr;
+  int rc = fail(nullptr, ADMM_E_HIP, "admm_edge_exp_values: a HIP call failed");
+  if (hipMalloc((void **)&dx, sizeof(float) * (size_t)n) == hipSuccess && hipMalloc((void **)&d1, sizeof(double) * (size_t)n) == hipSuccess &&
+      hipMalloc((void **)&d2, sizeof(double) * (size_t)n) == hipSuccess && hipMalloc((void **)&dn, (size_t)n) == hipSuccess &&
+      hipMemcpy(dx, x, sizeof(float) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess) {
+    hipLaunchKernelGGL(edge_exp_values_kernel, dim3(grid_for(n, kEdgeBlock)), dim3(kEdgeBlock), 0, 0, d1, d2, dn, dx, (long long)n);
+    if (hipGetLastError() == hipSuccess && hipMemcpy(own, d1, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess &&
+        hipMemcpy(lib, d2, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess &&
+        hipMemcpy(was_nan, dn, (size_t)n, hipMemcpyDeviceToHost) == hipSuccess)
+      rc = ADMM_OK;
+  }
+  (void)hipFree(dx); (void)hipFree(d1); (void)hipFree(d2); (void)hipFree(dn);
+  return rc;
+}
+
 const char *admm_last_error(const admm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 void admm_partition(int n, int nranks, int rank, int *start, int *count) {

@@ -56,6 +56,48 @@ __device__ __forceinline__ float edge_divide(float num, double den, double r) {
   return (float)(q1 != q1 ? q0 : q1);
 }
 
+// exp of a binary32 argument in binary64, for the three exponentials per table entry
+// (Tree.cpp:196, 219, 261).  The device library's algorithm with its coefficients, hence its
+// bits: n = rint(x log2 e), r = x - n ln 2 in two pieces, a degree-11 polynomial, ldexp.  The
+// library guards the ends of the range with two compares and two selects per call (beyond
+// 1024 the result is +inf, below -1075 it is 0); here the ARGUMENT is clamped to [-1076, 1025]
+// instead, where ldexp delivers +inf and 0 by itself: one instruction.  A clamp does not pass
+// a NaN on, so every call also notes whether its argument was one (`nan`: one bit per lane,
+// kept in a scalar register pair; one compare), and the caller turns the lane's sums into
+// NaN afterwards, which is what a NaN term makes of them in the reference.
+__device__ __forceinline__ double edge_exp(float c, unsigned long long &nan) {
+  nan |= __builtin_amdgcn_ballot_w64(c != c);
+  const double x = (double)__builtin_amdgcn_fmed3f(c, -1076.0f, 1025.0f);
+  auto K = [](unsigned long long bits) { return __builtin_bit_cast(double, bits); };
+  const double n = __builtin_rint(x * K(0x3ff71547652b82feull));
+  double r = __builtin_fma(n, K(0xbfe62e42fefa39efull), x);
+  r = __builtin_fma(n, K(0xbc7abc9e3b39803full), r);
+  double q = __builtin_fma(r, K(0x3e5ade156a5dcb37ull), K(0x3e928af3fca7ab0cull));
+  q = __builtin_fma(r, q, K(0x3ec71dee623fde64ull));
+  q = __builtin_fma(r, q, K(0x3efa01997c89e6b0ull));
+  q = __builtin_fma(r, q, K(0x3f2a01a014761f6eull));
+  q = __builtin_fma(r, q, K(0x3f56c16c1852b7b0ull));
+  q = __builtin_fma(r, q, K(0x3f81111111122322ull));
+  q = __builtin_fma(r, q, K(0x3fa55555555502a1ull));
+  q = __builtin_fma(r, q, K(0x3fc5555555555511ull));
+  q = __builtin_fma(r, q, K(0x3fe000000000000bull));
+  q = __builtin_fma(r, q, 1.0);
+  q = __builtin_fma(r, q, 1.0);
+  return __builtin_amdgcn_ldexp(q, (int)n);
+}
+
+// Values of edge_exp and of the device library's exp on a list of binary32 arguments
+// (accuracy and equality tests).
+__global__ void edge_exp_values_kernel(double *__restrict__ own, double *__restrict__ lib, unsigned char *__restrict__ was_nan,
+                                       const float *__restrict__ x, long long n) {
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+    unsigned long long nan = 0;
+    own[idx] = edge_exp(x[idx], nan);
+    lib[idx] = exp((double)x[idx]);
+    was_nan[idx] = (unsigned char)((nan >> (threadIdx.x & 63)) & 1);
+  }
+}
+
 // Tree.cpp:64-274 for one edge per KP-lane group.
 template <int KP>
 __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p) {
@@ -129,6 +171,7 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
   // (Tree.cpp:191-205: lane b sums over a) reads: its terms are added as the column is formed.
   constexpr int kLoadAhead = 8;
   float acc = 0.0f;
+  unsigned long long nan12 = 0;  // lanes that met a NaN argument of an exponential (see edge_exp)
   // how x / penaltyPrime is formed: 0 any value, 1 a power of two, 2 penaltyPrime = rho = 1 (the
   // drivers' values, admm.cpp:44-47: the multiplications by 1 are left out, x * 1 being x)
   auto derivatives = [&](auto how_c) {
@@ -161,7 +204,7 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
           const float epv = 0.0f - val;
           ep[a * LD + i] = epv;
           const float c = epv + np[a];
-          acc = (float)((double)acc + exp((double)c));
+          acc = (float)((double)acc + edge_exp(c, nan12));
         }
       }
     }
@@ -169,6 +212,8 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
   if (pp == 1.0f && rho == 1.0f) derivatives(std::integral_constant<int, 2>{});
   else if (pp_pow2) derivatives(std::integral_constant<int, 1>{});
   else derivatives(std::integral_constant<int, 0>{});
+  const float qnan = __builtin_nanf("");
+  if ((nan12 >> (threadIdx.x & 63)) & 1) acc = qnan;
   edge_lds_fence();
   buf[i] = acc;
   edge_lds_fence();
@@ -182,16 +227,21 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
   acc = 0.0f;
   float row_sum = 0.0f;
   const float np_own = np[i];
+  unsigned long long nan21 = 0, nan_row = 0;
   for (int b = 0; b < k; b++) {
     const float epv = ep[i * LD + b], n2 = np[KP + b];
     const float c = epv + n2;
-    acc = (float)((double)acc + exp((double)c));
+    acc = (float)((double)acc + edge_exp(c, nan21));
     float q = epv + np_own;
     q = q + n2;
-    const float ex = (float)exp((double)q);
+    const float ex = (float)edge_exp(q, nan_row);
     ep[i * LD + b] = ex;
     row_sum = row_sum + ex;
   }
+  // a NaN term makes the lane's message NaN; a NaN exponential of the edge marginal makes the
+  // row's sum NaN and with it, in the division below, every entry of the row, as in the reference
+  if ((nan21 >> (threadIdx.x & 63)) & 1) acc = qnan;
+  if ((nan_row >> (threadIdx.x & 63)) & 1) row_sum = qnan;
   buf[i] = acc;
   edge_lds_fence();
   sum = 0.0f;
@@ -251,8 +301,10 @@ __global__ __launch_bounds__(kEdgeBlock) void edge_solve_kernel(const EdgeArgs p
   if (wr) {
     const float n1 = pot_h[0] * mu1, n2 = pot_h[1] * mu2;
     oacc = (double)n1 + (double)n2;
-    // (the potentials are read a second time: a column of them kept in registers needs both
-    // loops unrolled by the lane count, which ran twenty times slower at 32 labels)
+    // (the potentials are read a second time.  Keeping the lane's column of them in registers needs
+    // the loop over the rows written out with fixed register names, 3 forms x 32 rows: the code no
+    // longer fits the instruction cache and the solve loses 6 % at 32 labels; an LDS copy halves
+    // the wavefronts per SIMD)
     for (int a0 = 0; a0 < k; a0 += kLoadAhead) {
       float pe_b[kLoadAhead];
 #pragma unroll

@@ -284,6 +284,14 @@ int admm_launch_info(admm_ctx *ctx, char *buf, int len);
  * For accuracy tests of that function; no counterpart in the reference. */
 int admm_edge_log_values(int device, const double *x, double *y, int64_t n);
 
+/* The exponential the edge solver takes three times per table entry
+ * (Tree.cpp:196, 219, 261), applied on the device to n binary32 arguments:
+ * own[i] = its value, lib[i] = the device library's exp of the same argument,
+ * was_nan[i] = 1 where the routine flagged a NaN argument (its value is then
+ * not the reference's; the solver turns the sums it enters into NaN).  For
+ * equality tests; no counterpart in the reference. */
+int admm_edge_exp_values(int device, const float *x, double *own, double *lib, unsigned char *was_nan, int64_t n);
+
 /* Number of HIP devices visible to this process (0 when there is none). */
 int admm_device_count(void);
 /* Free and total device memory of `device` in bytes as the HIP runtime reports
