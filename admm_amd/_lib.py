@@ -23,7 +23,7 @@ EXPORTS = [
     "admm_upload_pairwise", "admm_init", "admm_compute", "admm_communicate",
     "admm_communicate_group", "admm_exchange_counts", "admm_exchange_pack_host",
     "admm_exchange_unpack_host", "admm_update",
-    "admm_linear_objective", "admm_objective", "admm_objective_enqueue", "admm_objective_read", "admm_synchronize", "admm_finalize",
+    "admm_linear_objective", "admm_objective", "admm_objective_enqueue", "admm_objective_read", "admm_synchronize", "admm_query", "admm_finalize",
     "admm_download_labels", "admm_download_labels_static", "admm_download_consensus", "admm_download_state",
     "admm_state_size", "admm_partition", "admm_strip_info", "admm_edge_local_info", "admm_edge_local_vertices", "admm_edge_plan",
     "admm_comm_get_unique_id",
@@ -80,6 +80,7 @@ def _load():
         "admm_objective_enqueue": (C.c_int, [vp, C.c_int]),
         "admm_objective_read": (C.c_int, [vp, C.c_int, C.c_int, dp]),
         "admm_synchronize": (C.c_int, [vp]),
+        "admm_query": (C.c_int, [vp, C.POINTER(C.c_int)]),
         "admm_finalize": (C.c_int, [vp]),
         "admm_download_labels": (C.c_int, [vp, ip]),
         "admm_download_labels_static": (C.c_int, [vp, ip]),

@@ -2623,6 +2623,16 @@ int admm_synchronize(admm_ctx *c) {
   return ADMM_OK;
 }
 
+int admm_query(admm_ctx *c, int *busy) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!busy) return fail(c, ADMM_E_ARG, "null output");
+  const hipError_t e = hipStreamQuery(c->stream);
+  if (e != hipSuccess && e != hipErrorNotReady) return fail(c, ADMM_E_HIP, "hipStreamQuery failed: %s", hipGetErrorString(e));
+  *busy = e == hipErrorNotReady ? 1 : 0;
+  return ADMM_OK;
+}
+
 int admm_finalize(admm_ctx *c) {
   int rc = check_ctx(c);
   if (rc) return rc;

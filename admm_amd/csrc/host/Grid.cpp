@@ -79,9 +79,18 @@ void Grid::Load(const std::string &fname) {
 }
 
 void Grid::Save(const std::string &fname) {
-  if (vertPotentials.empty()) throw AdmmError(ADMM_E_STATE, "Generate, Load or Convert before Save");
+  if (vertPotentials.empty() && unaryFile.empty()) throw AdmmError(ADMM_E_STATE, "Generate, Load or Convert before Save");
   if (batch != 1) throw AdmmError(ADMM_E_ARG, "a graph file holds one graph (batch == 1)");
   const int k = numVertPotentials;
+  // A strip of several that loaded from a file keeps no host copy of the unaries (it reads its
+  // share when it uploads it): they are read back from that file here, as every rank of the
+  // reference can save what it loaded (Grid.cpp:1049-1131).
+  std::vector<float> fromStripFile;
+  if (vertPotentials.empty()) {
+    fromStripFile.assign((size_t)numGlobalVerts * k, 0.0f);
+    gf_check(admm_graphfile_read_unaries(unaryFile.c_str(), 0, numGlobalVerts, fromStripFile.data(), 1), "Save");
+  }
+  const std::vector<float> &vertPotentials = fromStripFile.empty() ? this->vertPotentials : fromStripFile;
   std::vector<int> el = edgeList;
   if (el.empty()) {
     el.resize((size_t)2 * std::max(1, numGlobalEdges));

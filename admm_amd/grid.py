@@ -168,16 +168,21 @@ class Grid:
     def Save(self, fname, version=0):
         """Grid::Save (Grid.cpp:1049-1131): the potentials this object holds,
         sign-flipped back into the scores a graph file holds."""
-        if self._unary is None:
+        if self._unary is None and self._unary_file is None:
             raise AdmmError(-2, "Load or Generate before Save")
         if self.batch != 1:
             raise ValueError("a graph file holds one graph (batch == 1)")
+        unary = self._unary
+        if unary is None:
+            # a strip of several that loaded from a file keeps no host copy of the unaries: read
+            # them back, as every rank of the reference can save what it loaded
+            unary = graphfile.read_unaries(self._unary_file, negate=True).reshape(-1)
         if self._edge_list is not None:
             el, V = self._edge_list, self._num_vertices
         else:
             el, V = grid_edges(self.rows, self.cols), self.rows * self.cols
         pw = -self._pairwise
-        graphfile.write(fname, V, el, -self._unary, pw.reshape(-1, self.k * self.k) if self._per_edge else pw.reshape(self.k, self.k),
+        graphfile.write(fname, V, el, -unary, pw.reshape(-1, self.k * self.k) if self._per_edge else pw.reshape(self.k, self.k),
                         rows=self.rows, cols=self.cols, version=version)
 
     def Convert(self, manifest):
@@ -327,6 +332,22 @@ class Grid:
 
     def Synchronize(self):
         self._ck(lib.admm_synchronize(self._h))
+
+    def Busy(self):
+        """True while work queued on this strip's stream is still running (no waiting)."""
+        b = C.c_int()
+        self._ck(lib.admm_query(self._h, C.byref(b)))
+        return bool(b.value)
+
+    def SynchronizeWithin(self, seconds):
+        """Synchronize() with a deadline: False if the stream is still busy after `seconds`."""
+        import time
+        t0 = time.monotonic()
+        while self.Busy():
+            if time.monotonic() - t0 > seconds:
+                return False
+            time.sleep(0.001)
+        return True
 
     def FinalizeOptimization(self):
         if self._h:

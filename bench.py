@@ -387,7 +387,13 @@ def main():
                 # sends everybody to the host-staged transport instead of
                 # leaving the others waiting at a barrier
                 try:
-                    g.Compute(); g.Communicate(); g.Update(); g.Synchronize()
+                    g.Compute(); g.Communicate(); g.Update()
+                    if not g.SynchronizeWithin(120.0):
+                        # a partner that never answers: leave with an error instead of holding the
+                        # node until the caller's limit (the queued exchange cannot be taken back)
+                        sys.stderr.write("rank %d: the RCCL exchange did not complete within 120 s\n" % rank)
+                        sys.stderr.flush()
+                        os._exit(3)
                 except A.AdmmError as e:
                     ok = 0
                     sys.stderr.write("rank %d: RCCL exchange failed: %s\n" % (rank, e))

@@ -174,6 +174,11 @@ int admm_objective_enqueue(admm_ctx *ctx, int slot);
 int admm_objective_read(admm_ctx *ctx, int slot, int n, double *linear);
 /* Waits for everything queued on the context's stream. */
 int admm_synchronize(admm_ctx *ctx);
+/* Without waiting: *busy = 1 while work queued on the context's stream is
+ * still running, 0 once it has all completed.  Lets a driver put a deadline on
+ * an exchange whose partner may never answer (the reference's MPI_Wait,
+ * Grid.cpp:1660-1662, has none). */
+int admm_query(admm_ctx *ctx, int *busy);
 /* Grid::FinalizeOptimization (Grid.cpp:1414-1416): releases the communicator. */
 int admm_finalize(admm_ctx *ctx);
 

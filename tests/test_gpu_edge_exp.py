@@ -34,7 +34,8 @@ def test_edge_exp_equals_the_device_library_bit_for_bit():
     assert not nan.any()
     assert np.array_equal(own.view(np.uint64), ref.view(np.uint64))
     # and rounded to binary32, where the solver stores it
-    assert np.array_equal(own.astype(np.float32).view(np.uint32), ref.astype(np.float32).view(np.uint32))
+    with np.errstate(over="ignore"):
+        assert np.array_equal(own.astype(np.float32).view(np.uint32), ref.astype(np.float32).view(np.uint32))
     assert own[x == np.inf][0] == np.inf and own[x == -np.inf][0] == 0.0
 
 

@@ -113,6 +113,14 @@ def test_cpp_driver_reads_the_file_it_saved(tmp_path):
             c3 = subprocess.run([ADMM, str(f), "--solver", solver, "--iters", "10", "--strips", "3"], capture_output=True, text=True, timeout=300)
             assert c3.returncode == 0, c3.stderr[-2000:]
             assert pick(c3.stderr) == pick(a.stderr)
+            # ... and a strip of several that loaded from a file can save it again
+            f2 = tmp_path / "saved_by_a_strip.nc"
+            c4 = subprocess.run([ADMM, str(f), "--solver", solver, "--iters", "1", "--strips", "3", "--save", str(f2)],
+                                capture_output=True, text=True, timeout=300)
+            assert c4.returncode == 0, c4.stderr[-2000:]
+            from admm_amd import graphfile as GF
+            assert np.array_equal(GF.read_unaries(str(f2), negate=False), GF.read_unaries(str(f), negate=False))
+            assert np.array_equal(GF.read_edges(str(f2)), GF.read_edges(str(f)))
     # a file that does not exist is an error message and a non-zero status
     c = subprocess.run([ADMM, str(tmp_path / "none.nc")], capture_output=True, text=True, timeout=60)
     assert c.returncode != 0 and "cannot open" in c.stderr

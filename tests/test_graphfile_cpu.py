@@ -388,3 +388,32 @@ def test_grid_convert_then_save_keeps_the_raw_values(tmp_path):
     assert np.array_equal(GF.read_pairwise(out, negate=False), pw)
     info = GF.read_info(out)
     assert (info.rows, info.cols, info.num_vertices, info.num_edges) == (-1, -1, V, E)
+
+
+def test_a_strip_that_loaded_from_a_file_can_save(tmp_path):
+    """A strip of several keeps no host copy of the unaries after Load(fname) (it reads its share
+    when it uploads it); Save reads them back from the file, as every rank of the reference can
+    save what it loaded (Grid.cpp:1049-1131)."""
+    import admm_amd as A
+    R, C, k = 7, 9, 3
+    rng = np.random.default_rng(11)
+    un = rng.standard_normal((R * C, k)).astype(np.float32)
+    W = rng.standard_normal((k, k)).astype(np.float32)
+    src = tmp_path / "grid.nc"
+    GF.write(src, R * C, A.grid_edges(R, C), un, W, rows=R, cols=C)
+    g = A.Grid(rank=1, nprocs=3)
+    g.SetPartitioner(A.ROW)
+    g.SetGlobalInfo(src)
+    g.Load(src)
+    assert g._unary is None
+    out = tmp_path / "again.nc"
+    g.Save(out)
+    assert np.array_equal(GF.read_unaries(out, negate=False), un)
+    assert np.array_equal(GF.read_edges(out), GF.read_edges(src))
+    table, shared = GF.shared_table(out, negate=False)
+    assert shared and np.array_equal(np.asarray(table).reshape(k, k), W)
+    empty = A.Grid()
+    empty.SetPartitioner(A.ROW)
+    with pytest.raises(A.AdmmError, match="before Save"):
+        empty.Save(tmp_path / "nothing.nc")
+
