@@ -407,8 +407,13 @@ SweepShape pick_shape(int KP, long long nchains) {
 // 32+ candidates per lane, or a split chain (scarce chains, so occupancy is not
 // the limit): room for 256 registers (8 or 16 labels packed several chains to a
 // wavefront spill at 128 registers).
-constexpr int sweep_gpb(int KP, int NS) { return (NS >= 4 || KP / NS >= 64) ? 4 : 8; }
-constexpr int sweep_minw(int KP, int NS) { return (KP / NS >= 32 || NS > 1) ? 2 : (KP >= 8 ? 3 : 4); }
+// 32 source labels per lane with one lane per label (two chains per wavefront, the dense 32-label
+// table at full occupancy): four wavefronts per SIMD in 128 registers, with operands fetched four
+// steps ahead and half of a step's messages read from LDS only after the arg-min work (MVLATE in
+// the kernel) - at 160 registers three wavefronts fitted, and the 4096 wavefronts of a 2048 x 2048
+// grid ran as one round of 3072 and a tail of 1024 alone on their SIMDs.
+constexpr int sweep_gpb(int KP, int NS) { return (NS >= 4 || KP / NS >= 64 || (KP == 32 && NS == 1)) ? 4 : 8; }
+constexpr int sweep_minw(int KP, int NS) { return (KP == 32 && NS == 1) ? 4 : (KP == 64 && NS == 1) ? 3 : ((KP / NS >= 32 || NS > 1) ? 2 : (KP >= 8 ? 3 : 4)); }
 
 template <int KP, int NS, bool DUAL>
 void launch_sweep_t(const ChainArgs &a, int blocks, hipStream_t s) {

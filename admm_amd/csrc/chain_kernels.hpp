@@ -996,11 +996,18 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
         // (a) this step's messages leave LDS, with the next group's labels
         //     and the operands of the group one block ahead behind them ...
         f4 mv[(A + 3) / 4];
+        // MVLATE: four wavefronts per SIMD leave 128 registers; the second half of the step's
+        // messages then leaves LDS only after the arg-min work of (b), whose registers it reuses
+        // (the other wavefronts of the SIMD cover its latency)
+        // (64 source labels per lane at three wavefronts per SIMD, 168 registers: four pieces, each
+        // read while the one before it is worked on)
+        constexpr int MVP = !RECOMP ? 1 : (A == 32 && MINW >= 4) ? 2 : (A == 64 && MINW >= 3) ? 4 : 1;  // pieces
+        constexpr bool MVLATE = MVP > 1;
         if (live && !POTTS && REC && TRUNC == 0) {
           if constexpr (A % 4 == 0) {
             const f4 *mp = reinterpret_cast<const f4 *>(Mrow + (RECOMP ? ((j * NS + u) & 1) * MROW : 0) + s * A);
 #pragma unroll
-            for (int q = 0; q < A / 4; q++) mv[q] = mp[q];
+            for (int q = 0; q < A / 4 / MVP; q++) mv[q] = mp[q];
           } else {
 #pragma unroll
             for (int q = 0; q < A; q++) mv[q / 4][q % 4] = Mrow[s * A + q];
@@ -1212,6 +1219,34 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
             if (j == 0 && u == 0) best = (tb == 0) ? (bvalid ? 0.0f : INF) : best;
             Mreg = th_own + best;
           }
+        } else if (MVLATE && live) {
+          // piece p + 1 leaves LDS, piece p is added to the lane's pairwise column and reduced to
+          // the minima of its groups of four
+          const f4 *mp = reinterpret_cast<const f4 *>(Mrow + ((j * NS + u) & 1) * MROW + s * A);
+          constexpr int PF = A / 4 / MVP;  // groups per piece
+          static_for<0, MVP>([&](auto p_c) {
+            constexpr int pi = decltype(p_c)::value;
+            if constexpr (pi + 1 < MVP) {
+#pragma unroll
+              for (int q = (pi + 1) * PF; q < (pi + 2) * PF; q++) mv[q] = mp[q];
+              if constexpr (MVP > 2) __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int q = pi * PF; q < (pi + 1) * PF; q++) {
+              const f2 lo = mv[q].xy + f2{Wr[4 * q + 0], Wr[4 * q + 1]};
+              const f2 hi = mv[q].zw + f2{Wr[4 * q + 2], Wr[4 * q + 3]};
+              const float c4[4] = {lo.x, lo.y, hi.x, hi.y};
+              c_prev[q] = min_of<4>(c4);
+            }
+            if constexpr (MVP > 2 && pi + 1 < MVP) __builtin_amdgcn_sched_barrier(0);
+          });
+          float best = __builtin_fminf(min_of<NG / 2>(c_prev), min_of<NG / 2>(c_prev + NG / 2));
+          best_prev = best;
+          if (j == 0 && u == 0) best = (tb == 0) ? (bvalid ? 0.0f : INF) : best;
+          const float Mnew = th_own + best;
+          wave_lds_fence();
+          s_M[wib][((((j * NS + u) & 1) ^ 1) * MROW) + m_addr[u]] = Mnew;
+          wave_lds_fence();
         } else if (live) {
           float c[A];
           if constexpr (A % 4 == 0) {
