@@ -338,3 +338,24 @@ def test_two_wavefronts_with_int16_counts_and_21_labels(monkeypatch):
     monkeypatch.setenv("ADMM_SWEEP_TWOWAVE", "1")
     monkeypatch.setenv("ADMM_LAM8", "0")
     _check(90, 200, 21, _unaries(90, 200, 21, 9, quant=4), _potts(21, 0.5), G=2, iters=5)
+
+
+@pytest.mark.parametrize("on", ["0", "1"])
+@pytest.mark.parametrize("R,C", [(150, 262), (75, 40), (33, 130)])
+def test_column_wavefront_pairs_on_one_die(R, C, on, monkeypatch):
+    """ADMM_SWEEP_PAIRXCD: the pairs of column wavefronts that share cache lines of the int8
+    counts are handed to workgroups eight apart (a permutation of every 16 mixed workgroups, the
+    rest in place).  Which workgroup sweeps which chains must not show in any result: more,
+    exactly and fewer than 16 mixed workgroups, forced on and off."""
+    import admm_amd as A
+    monkeypatch.setenv("ADMM_SWEEP_PAIRXCD", on)
+    monkeypatch.setenv("ADMM_SWEEP_TWOWAVE", "0")  # (a problem this small would otherwise run the two-wavefront kernels, whose workgroups are not mixed)
+    k = 32
+    _check(R, C, k, _unaries(R, C, k, 17, quant=4), _potts(k, 0.5), G=1, iters=4)
+    g = A.Grid()
+    g.SetPartitioner(A.ROW); g.SetPenalties(0.5, 1.0); g.SetGlobalInfo(R, C, k)
+    g.Load(_unaries(R, C, k, 17, quant=4), _potts(k, 0.5)); g.InitOptimization()
+    g.Compute()
+    info = g.LaunchInfo()
+    assert info["pair_xcd"] == int(on) and info["mixed_workgroups"] == 1 and info["multipliers"] == "int8", info
+    g.close()
