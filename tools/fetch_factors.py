@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Reduces the two counter passes of tools/gpu/r3_calibrate.sh (tools/fetch_calibration.hip
+"""Reduces the two counter passes of tools/gpu/calibrate_fetch.sh (tools/fetch_calibration.hip
 under rocprofv3 --pmc) to profiles/<tag>_fetch_calibration.json: for every read pattern
 the known bytes, FETCH_SIZE, the request counters it is derived from, and the factor
 known bytes / (FETCH_SIZE * 1024).
 
-    python tools/fetch_factors.py r03 gpurun_out/r3/cal
+    python tools/fetch_factors.py r03 gpurun_out/cal
 """
 import collections
 import csv
@@ -31,7 +31,7 @@ def main():
     raw = per_kernel(os.path.join(src, "raw", "cal_counter_collection.csv"))
     last = lambda d: d[sorted(d, key=int)[-1]]  # the second of the two runs of every kernel
     out = {"command": "rocprofv3 --pmc FETCH_SIZE -- tools/fetch_calibration ; rocprofv3 --pmc TCC_EA0_RDREQ_sum "
-                      "TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum -- tools/fetch_calibration (tools/gpu/r3_calibrate.sh)",
+                      "TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum -- tools/fetch_calibration (tools/gpu/calibrate_fetch.sh)",
            "patterns": {}}
     for name, b in known.items():
         fs = last(fetch[name]["FETCH_SIZE"])

@@ -3,7 +3,7 @@
 set -u
 export TMPDIR=/tmp
 root="${GRAFT_REPO_ROOT:-$PWD}"
-out="$root/gpurun_out/r3/cal"; mkdir -p "$out"
+out="$root/gpurun_out/cal"; mkdir -p "$out"
 cd /tmp
 timeout -k 10 120 "$root/tools/fetch_calibration" > "$out/known_bytes.json" || exit $?
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d "$out/fetch" -o cal --output-format csv -- "$root/tools/fetch_calibration" > "$out/fetch.log" 2>&1 || exit $?

@@ -1,4 +1,4 @@
-# Round 3, first GPU pass: the new tests, the bench line with its objective check, the self-launching two-rank bench.
+# The golden-pinned full-size tests, the bench line with its objective check, and the self-launching two-rank bench.
 set -u
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out/r3
