@@ -214,6 +214,10 @@ struct admm_ctx {
   // admm_communicate_group pulled the labels straight into the arrays the sweep reads
   // (pull_labels_kernel): the admm_update that follows has nothing left to transpose
   bool pulled = false;
+  // (rank 0's context remembers whether its group can pull: the group's size, its last context, the answer)
+  int pull_group_n = 0;
+  const admm_ctx *pull_group_last = nullptr;
+  bool pull_group_ok = false;
   label_t *xo_r_alt = nullptr, *xo_c_alt = nullptr;  // where a pull writes; admm_update swaps them in
 
   // the options the last Compute launch ran with (admm_launch_info)
@@ -2111,6 +2115,7 @@ int admm_exchange_unpack_host(admm_ctx *c, const int32_t *host_recv) {
   return ADMM_OK;
 }
 
+static bool group_pull_probe(admm_ctx **ctxs, int n);
 // Can every strip of the group read the others' label arrays from its own kernels?  Label
 // exchange only; all strips on one device, or on devices that grant each other peer access
 // (asked for here, once per pair).  ADMM_GROUP_PULL=0 (tuning and test knob) keeps the
@@ -2118,6 +2123,16 @@ int admm_exchange_unpack_host(admm_ctx *c, const int32_t *host_recv) {
 static bool group_pull_ok(admm_ctx **ctxs, int n) {
   if (n > kPullMaxStrips || !is_chain(ctxs[0]) || ctxs[0]->d.exchange != ADMM_EXCHANGE_LABELS) return false;
   if (const char *e = getenv("ADMM_GROUP_PULL")) if (atoi(e) == 0) return false;
+  // (the answer for this group is worked out once: it is a property of the strips' devices)
+  admm_ctx *first = ctxs[0];
+  if (first->pull_group_n == n && first->pull_group_last == ctxs[n - 1]) return first->pull_group_ok;
+  const bool ok = group_pull_probe(ctxs, n);
+  first->pull_group_n = n;
+  first->pull_group_last = ctxs[n - 1];
+  first->pull_group_ok = ok;
+  return ok;
+}
+static bool group_pull_probe(admm_ctx **ctxs, int n) {
   for (int g = 0; g < n; g++)
     for (int h = 0; h < n; h++) {
       const int dg = ctxs[g]->d.device, dh = ctxs[h]->d.device;
