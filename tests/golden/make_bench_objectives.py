@@ -4,7 +4,8 @@
 The trajectories bench.py times, solved by oracle/admm_oracle.c on the host: for every
 chain workload of bench.py (LCG seed 1234, penalties 0.5 / 1.0 unless the name says
 otherwise) the linear objective after every iteration and, at the iteration counts the
-benchmark is run with (warmup + steps = 25 and 55), the decoded energy, the dual bound
+benchmark is run with (warmup + steps = 25 and 55; the headline workload also 100, 250 and
+500, the length of the reference's own loop, admm.cpp:78), the decoded energy, the dual bound
 and SHA-256 digests of the decoded labels, of the row chains' and the column chains'
 labels (int32, little endian, grid-major) and of the row chains' multipliers (binary32).  bench.py reads
 this file and compares what the HIP path left behind after its timed region with the
@@ -29,6 +30,7 @@ from oracle import oracle as O  # noqa: E402
 
 OUT = os.path.join(HERE, "bench_objectives.json")
 CHECKPOINTS = (25, 55)
+LONG_CHECKPOINTS = {"2048x2048_k32_potts": (25, 55, 100, 250, 500)}
 SEED = 1234
 
 # name: rows, cols, k, batch, pairwise, penalty
@@ -43,7 +45,7 @@ CASES = {
 }
 
 
-def run_case(rows, cols, k, batch, pairwise, penalty):
+def run_case(rows, cols, k, batch, pairwise, penalty, CHECKPOINTS=CHECKPOINTS):
     last = max(CHECKPOINTS)
     _, st0 = O.lcg_fill(SEED, rows * cols * k)
     W = O.pairwise_table(pairwise, k, st0)  # the table follows grid 0's draws (Grid.Generate)
@@ -88,7 +90,7 @@ def main():
         doc = json.load(open(OUT))
     for n in names:
         t0 = time.time()
-        doc[n] = run_case(*CASES[n])
+        doc[n] = run_case(*CASES[n], CHECKPOINTS=LONG_CHECKPOINTS.get(n, CHECKPOINTS))
         sys.stderr.write("%s: %.0f s\n" % (n, time.time() - t0))
         with open(OUT, "w") as f:
             json.dump(doc, f, indent=1, sort_keys=True)

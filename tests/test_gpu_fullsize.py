@@ -112,6 +112,39 @@ def test_bench_trajectory_55_iterations_headline():
     g.close()
 
 
+def test_the_references_loop_of_500_iterations_headline():
+    """The reference's driver runs 500 iterations (admm.cpp:78).  The same loop at the headline
+    size against the committed oracle run: the linear objective of every iteration, and at
+    iterations 100, 250 and 500 the decoded labels, both sets of chain labels, the multipliers,
+    the decoded energy and the dual bound.  The int8 counts are scanned some thirty times on
+    the way."""
+    import admm_amd as A
+    case = json.load(open(GOLDEN))["2048x2048_k32_potts"]
+    marks = [c for c in (100, 250, 500) if str(c) in case["at"]]
+    assert marks == [100, 250, 500], "tests/golden/bench_objectives.json holds no 500-iteration run"
+    g = A.Grid()
+    g.SetPartitioner(A.ROW)
+    g.SetPenalties(case["penalty"], 1.0)
+    g.SetGlobalInfo(case["rows"], case["cols"], case["k"], batch=case["batch"])
+    g.Generate(seed=case["seed"], pairwise=case["pairwise"])
+    g.InitOptimization()
+    g._unary = None
+    for it in range(1, 501):
+        g.Compute(); g.Communicate(); g.Update(); g.ObjectiveEnqueue(it)
+        if it in marks:
+            at = case["at"][str(it)]
+            assert _sha(g.Labels(), "<i4") == at["labels_sha256"], "decoded labels after %d iterations" % it
+            assert _sha(g.State(13), "<i4") == at["xrow_sha256"], "row chains' labels after %d iterations" % it
+            assert _sha(g.State(14), "<i4") == at["xcol_sha256"], "column chains' labels after %d iterations" % it
+            assert _sha(g.State(10), "<f4") == at["lambda_row_sha256"], "multipliers after %d iterations" % it
+            p, d = g.Objective()
+            assert abs(p - at["primal"]) <= 1e-9 * abs(at["primal"]) and abs(d - at["dual"]) <= 1e-9 * abs(at["dual"]), it
+    lin = g.ObjectiveRead(1, 500)
+    exp = np.array(case["linear"][:500])
+    assert np.all(np.abs(lin - exp) <= 1e-9 * np.abs(exp)), "linear objective trace"
+    g.close()
+
+
 def test_bench_trajectory_int8_counts_widen_in_mid_run_at_full_size(monkeypatch):
     """A scan threshold of 1 makes the first scan that sees a non-zero count (the one after
     sweep 5) turn the arrays into int16 while the run goes on; the results must not notice.
