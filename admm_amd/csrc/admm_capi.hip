@@ -447,17 +447,20 @@ void launch_sweep_potts_split_t(const ChainArgs &a, int blocks, hipStream_t s, b
   else hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, kSplitGpb, 4, false, true, false, false, false, true>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
 }
 
+// Steps per unrolled block of the Potts kernels (= how far ahead the operands are fetched, in one
+// burst per block): 16 where several steps of a chain share a 128-byte line (32: spills), 8 with
+// 32 and 64 labels (the records of the path compression are one per block of eight steps).
+constexpr int potts_gpb(int KP) { return KP <= 16 ? 16 : 8; }
 template <int KP, bool PCOMP = false>
 void launch_sweep_potts_t(const ChainArgs &a, int blocks, hipStream_t s) {
-  // a step needs few registers: four wavefronts per SIMD, operands fetched 8 steps ahead
-  // (16 ahead changes nothing: the kernel moves its bytes at the rate a streaming kernel does)
-  hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, false, PCOMP>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
+  // a step needs few registers: four wavefronts per SIMD, operands fetched a block ahead (potts_gpb)
+  hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, potts_gpb(KP), 4, false, true, false, PCOMP>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
 }
 template <int KP, bool PCOMP = false>
 void launch_sweep_potts16_t(const ChainArgs &a, int blocks, hipStream_t s, bool lam8) {
-  // (operands 16 steps ahead instead of 8: 1 to 2 % slower; 32: spills)
-  if (lam8) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, PCOMP, true>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
-  else hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, 8, 4, false, true, true, PCOMP>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
+  // (32 and 64 labels with a load per step: operands 16 steps ahead instead of 8 were 1 to 2 % slower)
+  if (lam8) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, potts_gpb(KP), 4, false, true, true, PCOMP, true>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
+  else hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, potts_gpb(KP), 4, false, true, true, PCOMP>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
 }
 
 // Path compression in the Potts kernel (the forward pass tracks, per block of eight
@@ -2929,7 +2932,7 @@ int admm_sweep_kernel_name(admm_ctx *c, char *buf, int len) {
     const int CPW = 64 / sh.KP;
     const int waves = 2 * ((c->d.batch * c->st.nrows + CPW - 1) / CPW) + 2 * ((c->d.batch * c->st.ncols + CPW - 1) / CPW);
     const bool two = twowave_chosen(sh.KP, waves);
-    snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, 1, %d, 4, false, true, %s, %s, %s, %s, 0>", sh.KP, two ? kSplitGpb : 8, c->lam16 ? "true" : "false",
+    snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, 1, %d, 4, false, true, %s, %s, %s, %s, 0>", sh.KP, two ? kSplitGpb : potts_gpb(sh.KP), c->lam16 ? "true" : "false",
              (!two && pcomp_chosen(sh.KP, waves)) ? "true" : "false", (c->lam16 && c->lam8) ? "true" : "false", two ? "true" : "false");
   } else if (trunc_chosen(c, sh))
   {
