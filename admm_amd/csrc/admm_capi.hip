@@ -440,12 +440,16 @@ bool twowave_chosen(int KP, int waves, bool trunc = false) {
 // (the shell fetches its operands sixteen steps ahead there: 3 % over eight, 0.118 -> 0.115 ms per
 // sweep for a strip of eight, 0.145 -> 0.139 for one of four)
 constexpr int kSplitGpb = 16;
-template <int KP>
+// MINW: 2 where every wavefront of the launch has a SIMD to itself (that instance fetches a block's
+// operands in one burst, see the kernel), 4 otherwise.
+template <int KP, int MINW>
 void launch_sweep_potts_split_t(const ChainArgs &a, int blocks, hipStream_t s, bool lam16, bool lam8) {
-  if (lam8) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, kSplitGpb, 4, false, true, true, false, true, true>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
-  else if (lam16) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, kSplitGpb, 4, false, true, true, false, false, true>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
-  else hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, kSplitGpb, 4, false, true, false, false, false, true>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
+  if (lam8) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, kSplitGpb, MINW, false, true, true, false, true, true>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
+  else if (lam16) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, kSplitGpb, MINW, false, true, true, false, false, true>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
+  else hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, kSplitGpb, MINW, false, true, false, false, false, true>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
 }
+// (the split doubles the wavefronts; the chip has 1024 SIMDs)
+inline bool split_lone(int waves) { return 2 * waves <= 1024; }
 
 // Steps per unrolled block of the Potts kernels (= how far ahead the operands are fetched, in one
 // burst per block): 16 where several steps of a chain share a 128-byte line (32: spills), 8 with
@@ -574,7 +578,9 @@ int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
   if (potts && twowave_chosen(sh.KP, w)) {
     a.mix_blocks = 0;
     a.red_block = w / 2;
-    launch_sweep_potts_split_t<32>(a, w_split, s, c->lam16, c->lam16 && c->lam8);  // a workgroup per group of chains
+    // a workgroup per group of chains
+    if (split_lone(w)) launch_sweep_potts_split_t<32, 2>(a, w_split, s, c->lam16, c->lam16 && c->lam8);
+    else launch_sweep_potts_split_t<32, 4>(a, w_split, s, c->lam16, c->lam16 && c->lam8);
     HIP_TRY(c, hipGetLastError());
     return ADMM_OK;
   }
@@ -2932,7 +2938,8 @@ int admm_sweep_kernel_name(admm_ctx *c, char *buf, int len) {
     const int CPW = 64 / sh.KP;
     const int waves = 2 * ((c->d.batch * c->st.nrows + CPW - 1) / CPW) + 2 * ((c->d.batch * c->st.ncols + CPW - 1) / CPW);
     const bool two = twowave_chosen(sh.KP, waves);
-    snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, 1, %d, 4, false, true, %s, %s, %s, %s, 0>", sh.KP, two ? kSplitGpb : potts_gpb(sh.KP), c->lam16 ? "true" : "false",
+    snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, 1, %d, %d, false, true, %s, %s, %s, %s, 0>", sh.KP, two ? kSplitGpb : potts_gpb(sh.KP),
+             (two && split_lone(waves)) ? 2 : 4, c->lam16 ? "true" : "false",
              (!two && pcomp_chosen(sh.KP, waves)) ? "true" : "false", (c->lam16 && c->lam8) ? "true" : "false", two ? "true" : "false");
   } else if (trunc_chosen(c, sh))
   {

@@ -1027,14 +1027,23 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
           }
           // The operands of the next block: one load per step, or (PFB) all of them behind the
           // block's last step.  Back to back, the loads of consecutive steps that share a
-          // 128-byte line (8 labels: four steps of a row chain, 16 labels: two) are served
-          // by one fetch of it, and consecutive lines reach the memory system together: 256
-          // grids of 256 x 256, k = 8: 0.433 -> 0.378 ms per sweep (with blocks of 16 steps);
-          // 2048 x 2048, k = 32: Potts 0.348 -> 0.345 ms, dense table 0.695 -> 0.684.  With 64
-          // source labels per lane (1024 x 1024, k = 64: 0.574 -> 0.594 ms) and for a shell
-          // wavefront that is alone on its SIMD the first steps of the next block would wait
-          // for them: those keep a load per step.
-          constexpr int PFB = (!SPLIT && !DUAL && (POTTS || (RECOMP && A == 32))) ? GPB : 1;
+          // 128-byte line (8 labels: four steps of a row chain, 16 labels: two; the int8 counts
+          // of 32 labels: four) are served by one fetch of it, and consecutive lines reach the
+          // memory system together.  The first steps of the next block then wait for their
+          // operands unless other wavefronts of the SIMD have work, so it pays where the SIMDs
+          // are full - 256 grids of 256 x 256, k = 8: 0.433 -> 0.378 ms per sweep (with blocks of
+          // 16 steps); 2048 x 2048, k = 32: 0.348 -> 0.345 ms - and loses where they are not
+          // (two strips of that grid, two wavefronts per SIMD: 0.231 -> 0.245 ms).  Up to 16
+          // labels the kernel always fetches in bursts; with 32 and 64 the instance with path
+          // compression does, which the host launches on a full chip only.  The general
+          // kernel keeps a load per step (32 labels, full chip: + 1 %; 64 labels: - 3 %; 16: no
+          // change).
+          // A shell wavefront (SPLIT) that has its SIMD to itself gains by the burst as well
+          // (one strip of eight of the 2048 x 2048 grid: 0.115 -> 0.110 ms per sweep); sharing
+          // the SIMD with another chain's it loses (one strip of four: 0.140 -> 0.146).  The
+          // host launches the instance built for two wavefronts per SIMD (MINW = 2) in the
+          // first case, and that is the one that fetches in bursts.
+          constexpr int PFB = (POTTS && !DUAL && (SPLIT ? MINW == 2 : (KP <= 16 || PCOMP))) ? GPB : 1;
           if constexpr (PFB == 1) {
             const unsigned poff = goff + (unsigned)BLK * sstep;
             pth[j] = buf_load(th_rs, poff);
