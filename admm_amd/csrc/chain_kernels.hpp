@@ -1347,8 +1347,11 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // handed out first finish a quarter earlier than the last ones, and the end
   // of the launch runs on a quarter of the wavefronts).  Issue priorities that
   // rotate every 64 steps, offset by the workgroup's place in the launch, even
-  // that out a little: 2 to 5 % on every workload with more than one wavefront
-  // per SIMD.  (s_setprio takes an immediate, hence the switch.)
+  // that out a little: 6 to 7 % with four wavefronts per SIMD (2048 x 2048, k = 32, Potts
+  // and dense table), nothing either way with one or two, and with the three wavefronts
+  // per SIMD of the 64-label general kernel it costs 2.6 % (1024 x 1024: 1698 against
+  // 1742 it/s), so that kernel leaves the priorities alone.  A period of 32 or of 128 steps
+  // is no better than 64.  (s_setprio takes an immediate, hence the switch.)
   const int prio_slot = (int)((long long)blockIdx.x * 4 / gridDim.x);
   auto set_prio = [&](int p) {
     switch (p & 3) {
@@ -1366,7 +1369,7 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
   // alone on its SIMD has nothing to cover with.
   auto chunk = [&](const int t0, auto whole_tag) {
     constexpr bool WHOLE = decltype(whole_tag)::value;
-    set_prio(prio_slot + t0 / kChunk);
+    if constexpr (!(RECOMP && A == 64)) set_prio(prio_slot + t0 / kChunk);
     if (!DUAL) {
       // labels of chunk t0 are in LDS; fetch the next chunk's while this one runs
       if constexpr (XNEXT) labels_fetch(t0 + kChunk);
