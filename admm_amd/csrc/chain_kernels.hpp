@@ -1047,10 +1047,11 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
           // change).
           // A shell wavefront (SPLIT) that has its SIMD to itself gains by the burst as well
           // (one strip of eight of the 2048 x 2048 grid: 0.115 -> 0.110 ms per sweep); sharing
-          // the SIMD with another chain's it loses (one strip of four: 0.140 -> 0.146).  The
+          // the SIMD with another chain's it loses (one strip of four: 0.140 -> 0.146, and as
+          // much with the shell's issue priority raised).  The
           // host launches the instance built for two wavefronts per SIMD (MINW = 2) in the
           // first case, and that is the one that fetches in bursts.
-          constexpr int PFB = (POTTS && !DUAL && (SPLIT ? MINW == 2 : (KP <= 16 || PCOMP))) ? GPB : 1;
+                    constexpr int PFB = (POTTS && !DUAL && (SPLIT ? MINW == 2 : (KP <= 16 || PCOMP))) ? GPB : 1;
           if constexpr (PFB == 1) {
             const unsigned poff = goff + (unsigned)BLK * sstep;
             pth[j] = buf_load(th_rs, poff);
@@ -1414,6 +1415,11 @@ __global__ __launch_bounds__(kChainBlock, MINW) void chain_sweep_kernel(const Ch
     // round ib - 1; a workgroup barrier ends every round.  All four wavefronts of the
     // workgroup run the same number of rounds (the longer half's).
     const int nblk = (Lhalf + BLK - 1) / BLK;
+    // Where two chains' wavefronts share a SIMD the shell goes first: it runs a block ahead of
+    // the recursion and its loads are what everything else waits for (one strip of four of the
+    // 2048 x 2048 grid: 0.140 -> 0.131 ms per sweep; alone on its SIMD it makes no difference).
+    // (priority 3 instead of 2: the same)
+    if (role == 1) __builtin_amdgcn_s_setprio(2);
     typedef std::integral_constant<int, 1> shell_t;
     typedef std::integral_constant<int, 2> rec_t;
     // Each role has its rounds in loops of its own, whole blocks apart from the last, partial
