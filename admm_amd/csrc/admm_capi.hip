@@ -430,7 +430,9 @@ void launch_sweep_t(const ChainArgs &a, int blocks, hipStream_t s) {
 // whatever its kind, so halving the instructions per wavefront and step is what shortens the
 // sweep: 0.178 -> 0.116 ms per sweep for a strip of eight, 0.159 -> 0.143 ms for one of four
 // (there the second wavefront shares a SIMD with another chain's); with two wavefronts per SIMD
-// to begin with (a strip of two) it changes nothing.  ADMM_SWEEP_TWOWAVE=0/1 (tuning and test
+// to begin with (a strip of two) it changes nothing.  (Since then 0.110 and 0.132 ms: blocks of
+// 16 steps, operands in one burst for a lone shell wavefront, issue priority for a shell that
+// shares its SIMD - see the kernel.)  ADMM_SWEEP_TWOWAVE=0/1 (tuning and test
 // knob) overrides.
 bool twowave_chosen(int KP, int waves, bool trunc = false) {
   if (KP != 32 && !trunc) return false;
