@@ -1887,7 +1887,7 @@ int admm_compute(admm_ctx *c) {
 
 namespace {
 
-const ExchangePlan &plan_of(admm_ctx *c) {
+extern "C++" const ExchangePlan &plan_of(admm_ctx *c) {  // (a reference to a C++ type: not for the C linkage of the block around it)
   if (c->plan_ready) return c->plan;
   const admm_desc &d = c->d;
   const int G = d.nranks;
