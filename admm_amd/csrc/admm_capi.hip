@@ -417,7 +417,9 @@ SweepShape pick_shape(int KP, long long nchains) {
 // the kernel) - at 160 registers three wavefronts fitted, and the 4096 wavefronts of a 2048 x 2048
 // grid ran as one round of 3072 and a tail of 1024 alone on their SIMDs.
 constexpr int sweep_gpb(int KP, int NS) { return (NS >= 4 || KP / NS >= 64 || (KP == 32 && NS == 1)) ? 4 : 8; }
-constexpr int sweep_minw(int KP, int NS) { return (KP == 32 && NS == 1) ? 4 : (KP == 64 && NS == 1) ? 3 : ((KP / NS >= 32 || NS > 1) ? 2 : (KP >= 8 ? 3 : 4)); }
+// (2 and 4 labels with one lane per label: 32 and 16 chains per wavefront, whose label staging takes
+// the registers of one and of three wavefronts per SIMD)
+constexpr int sweep_minw(int KP, int NS) { return (KP == 32 && NS == 1) ? 4 : (KP == 64 && NS == 1) ? 3 : ((KP / NS >= 32 || NS > 1) ? 2 : (KP >= 4 ? 3 : 1)); }
 
 template <int KP, int NS, bool DUAL>
 void launch_sweep_t(const ChainArgs &a, int blocks, hipStream_t s) {
@@ -443,7 +445,7 @@ bool twowave_chosen(int KP, int waves, bool trunc = false) {
 // sweep for a strip of eight, 0.145 -> 0.139 for one of four)
 constexpr int kSplitGpb = 16;
 // MINW: 2 where every wavefront of the launch has a SIMD to itself (that instance fetches a block's
-// operands in one burst, see the kernel), 4 otherwise.
+// operands in one burst, see the kernel), 3 otherwise (two wavefronts per SIMD is all such a launch has).
 template <int KP, int MINW>
 void launch_sweep_potts_split_t(const ChainArgs &a, int blocks, hipStream_t s, bool lam16, bool lam8) {
   if (lam8) hipLaunchKernelGGL((chain_sweep_kernel<KP, 1, kSplitGpb, MINW, false, true, true, false, true, true>), dim3(blocks), dim3(kChainBlock), sweep_pad_lds(), s, a);
@@ -582,7 +584,7 @@ int launch_sweep(admm_ctx *c, ChainArgs &a, SweepShape sh) {
     a.red_block = w / 2;
     // a workgroup per group of chains
     if (split_lone(w)) launch_sweep_potts_split_t<32, 2>(a, w_split, s, c->lam16, c->lam16 && c->lam8);
-    else launch_sweep_potts_split_t<32, 4>(a, w_split, s, c->lam16, c->lam16 && c->lam8);
+    else launch_sweep_potts_split_t<32, 3>(a, w_split, s, c->lam16, c->lam16 && c->lam8);
     HIP_TRY(c, hipGetLastError());
     return ADMM_OK;
   }
@@ -2941,7 +2943,7 @@ int admm_sweep_kernel_name(admm_ctx *c, char *buf, int len) {
     const int waves = 2 * ((c->d.batch * c->st.nrows + CPW - 1) / CPW) + 2 * ((c->d.batch * c->st.ncols + CPW - 1) / CPW);
     const bool two = twowave_chosen(sh.KP, waves);
     snprintf(buf, (size_t)len, "chain_sweep_kernel<%d, 1, %d, %d, false, true, %s, %s, %s, %s, 0>", sh.KP, two ? kSplitGpb : potts_gpb(sh.KP),
-             (two && split_lone(waves)) ? 2 : 4, c->lam16 ? "true" : "false",
+             two ? (split_lone(waves) ? 2 : 3) : 4, c->lam16 ? "true" : "false",
              (!two && pcomp_chosen(sh.KP, waves)) ? "true" : "false", (c->lam16 && c->lam8) ? "true" : "false", two ? "true" : "false");
   } else if (trunc_chosen(c, sh))
   {
